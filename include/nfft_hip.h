@@ -1,0 +1,112 @@
+/* nfft_hip.h -- C ABI of the MI355X-native NFFT forward/adjoint hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.  Every
+ * entry point names the interface of the reference (dominikbuenger/torch_nfft)
+ * it replaces.  All pointers are DEVICE pointers unless stated otherwise; all
+ * work is enqueued on `stream` (a hipStream_t passed as void*) and the calls
+ * return without synchronising the device.  Temporaries come from a
+ * caller-provided workspace (the host side hands in memory from its caching
+ * allocator), so no entry point allocates or frees device memory.
+ *
+ * Data layouts (reference: docs/source/theory/dataformat.rst:19-63):
+ *   pos    float32 [n, dim]            points on the torus, nominally in [-1/2, 1/2)
+ *   batch  int64   [n] or NULL         sorted point-set index of every point
+ *   x      spatial coefficients  [n, C]            float32 (real) or complex64
+ *   xhat   spectral coefficients [B, N^dim, C]     float32 (real) or complex64;
+ *          frequency k in [-N/2, N/2) is stored at index k + N/2 on every axis
+ * Complex data is interleaved (re, im) float32 pairs, i.e. torch.complex64.
+ *
+ * Return value: 0 on success, otherwise one of the NFFT_HIP_E* codes;
+ * nfft_hip_last_error() returns a human-readable message for the calling thread.
+ */
+#ifndef NFFT_HIP_H
+#define NFFT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFFT_HIP_OK 0
+#define NFFT_HIP_EINVAL 1     /* "Input mismatch" (reference: CHECK_INPUT, csrc/cuda/cuda_utils.cu:3) */
+#define NFFT_HIP_EWORKSPACE 2 /* workspace missing or too small */
+#define NFFT_HIP_EFFT 3       /* rocFFT plan creation/execution failed (reference: "Failed to create CUFFT plan", core_cuda.cu:255-268) */
+#define NFFT_HIP_EHIP 4       /* HIP runtime error (reference aborts the process, cuda_utils.cu:7-14; we report) */
+
+#define NFFT_HIP_ABI_VERSION 1
+
+int nfft_hip_abi_version(void);
+const char *nfft_hip_last_error(void);
+
+/* Problem description shared by the entry points below.
+ * Mirrors the arguments of the reference operators (csrc/core.cpp:43-105):
+ *   dim           pos.size(1), 1..3                       (core_cuda.cu:50-51)
+ *   num_points    pos.size(0)
+ *   num_columns   x.numel() / num_points  resp.  x.numel() / (B * N^dim)   (core_cuda.cu:84, 108-113)
+ *   batch_size    batch[-1] + 1, or 1 when batch is NULL  (core_cuda.cu:60-65) -- read back by the HOST side
+ *   N             bandwidth (even, >= 2);  m  window cutoff, 1 <= m, 2m+2 <= 2N
+ */
+typedef struct nfft_hip_problem {
+    int32_t dim;
+    int64_t num_points;
+    int64_t num_columns;
+    int64_t batch_size;
+    int64_t N;
+    int64_t m;
+} nfft_hip_problem;
+
+/* Bytes of workspace needed by nfft_hip_adjoint / nfft_hip_forward for this problem
+ * (creates and caches the rocFFT plans on the current device; returns < 0 on error).
+ * x_is_complex / real_output as in the calls below. */
+int64_t nfft_hip_adjoint_workspace_bytes(const nfft_hip_problem *p, int x_is_complex, int real_output);
+int64_t nfft_hip_forward_workspace_bytes(const nfft_hip_problem *p, int x_is_complex, int real_output);
+
+/* Adjoint NFFT:  y[b, k+N/2, c] ~= sum_{i: batch[i]=b} x[i,c] exp(+2 pi i k.pos[i]).
+ * Replaces nfft_adjoint_cuda (csrc/cuda/core_cuda.cu:144-336), i.e. the operator
+ * torch_nfft::nfft_adjoint(pos, x, batch, N, m, real_output) (csrc/core.cpp:43-55, 177).
+ *   x  [n, C] float32 (x_is_complex = 0) or complex64 (x_is_complex = 1)
+ *   y  [B, N^dim, C] complex64, or float32 holding the real part when real_output != 0;
+ *      every element is written (the caller need not zero it). */
+int nfft_hip_adjoint(const nfft_hip_problem *p, const float *pos, const void *x, int x_is_complex,
+                     const int64_t *batch, int real_output, void *y,
+                     void *workspace, int64_t workspace_bytes, void *stream);
+
+/* Forward NFFT:  y[i,c] ~= sum_k xhat[batch[i], k+N/2, c] exp(-2 pi i k.pos[i]).
+ * Replaces nfft_forward_cuda (csrc/cuda/core_cuda.cu:340-531), i.e. the operator
+ * torch_nfft::nfft_forward(pos, x, batch, m, real_output) (csrc/core.cpp:94-105, 178).
+ *   xhat [B, N^dim, C] float32 or complex64;  y [n, C] complex64 or float32 (real part). */
+int nfft_hip_forward(const nfft_hip_problem *p, const float *pos, const void *xhat, int x_is_complex,
+                     const int64_t *batch, int real_output, void *y,
+                     void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ---- stage-level entry points (used by the parity tests and by bench.py to time
+ * the spreading kernel on its own; the two calls above are built from them) ---- */
+
+/* Size in bytes of a point plan (tile-sorted copy of the points) for this problem. */
+int64_t nfft_hip_plan_bytes(const nfft_hip_problem *p);
+
+/* Bin the points into grid tiles.  Replaces compute_shifts_kernel + compute_psi_kernel
+ * (csrc/cuda/spatial_window_operations.cu:38-97, launched at core_cuda.cu:188-211): instead of
+ * materialising shifts and 2m+2 window values per point and axis in HBM, the points are
+ * counting-sorted by tile and the window is re-evaluated in registers by the consumers. */
+int nfft_hip_plan_points(const nfft_hip_problem *p, const float *pos, const int64_t *batch,
+                         void *plan, int64_t plan_bytes, void *stream);
+
+/* Spreading (adjoint gridding):  grid[(b*Cr + cr), u] += xr[i, cr] * prod_k psi_k(i, u_k)
+ * over real columns cr (a complex x is viewed as 2C real columns).  Replaces
+ * real_/complex_adjoint_window_convolution_kernel (spatial_window_operations.cu:103-211).
+ *   grid  float32 [B*Cr, (2N)^dim] real planes; zero-filled by this call.
+ *   scratch  float32 [n * Cr] for the tile-ordered copy of xr. */
+int nfft_hip_spread(const nfft_hip_problem *p, const void *plan, const float *xr, int64_t real_columns,
+                    float *grid, float *scratch, void *stream);
+
+/* Interpolation (forward gather):  yr[i, cr] = sum_u grid[(b*Cr + cr), u] * prod_k psi_k(i, u_k).
+ * Replaces complex_/real_forward_window_convolution_kernel (spatial_window_operations.cu:214-332). */
+int nfft_hip_interpolate(const nfft_hip_problem *p, const void *plan, const float *grid,
+                         int64_t real_columns, float *yr, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFFT_HIP_H */

@@ -18,7 +18,6 @@ _lib = None
 def build(force=False):
     src = os.path.join(_HERE, "ndft_c.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        # -march=native objects must be rebuilt on the machine that runs them
         subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
     return _SO
 

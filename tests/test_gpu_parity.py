@@ -1,0 +1,333 @@
+"""GPU parity tests: the HIP path (through the C ABI, via torch_nfft_amd) against the oracle.
+
+Tolerances (fp32, stated here as the contract):
+  T1  HIP vs the float64 restatement of the reference's algorithm (oracle/nfft_ref.py):
+      relative L2 <= 2e-5  (fp32 accumulation of up to n terms; atomics reorder the sums)
+  T2  HIP vs the exact NDFT (golden vectors frozen from the reference's torch_nfft/ndft.py, or
+      oracle/ndft.py): relative L2 <= 2e-2 (m=2), 3e-3 (m=3), 5e-4 (m=4), 2e-5 (m=8)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+from oracle import ndft, nfft_ref
+
+pytestmark = pytest.mark.gpu
+
+T1 = 2e-5
+T2 = {1: 2e-1, 2: 2e-2, 3: 3e-3, 4: 5e-4, 5: 1e-4, 6: 5e-5, 7: 3e-5, 8: 2e-5}
+
+
+@pytest.fixture(scope="module")
+def tn():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import torch_nfft_amd
+    return torch_nfft_amd
+
+
+def dev(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+# ----------------------------------------------------------------------------- golden vectors
+
+def test_golden_g1_adjoint_2d_batched(tn):
+    g = load_golden("g1_adjoint_2d_batched")
+    y = tn.nfft_adjoint(dev(g["x"]), dev(g["pos"]), dev(g["batch"]), bandwidth=16, cutoff=4)
+    assert y.shape == (3, 16, 16, 10) and y.dtype == torch.complex64
+    assert rel_l2(host(y), g["y_adjoint"]) < T2[4]
+    ref = nfft_ref.nfft_adjoint(g["x"], g["pos"], g["batch"], N=16, m=4)
+    assert rel_l2(host(y), ref) < T1
+
+
+def test_golden_g2_forward_2d(tn):
+    g = load_golden("g2_forward_2d")
+    y = tn.nfft_forward(dev(g["x"]), dev(g["pos"]), None, cutoff=4)
+    assert y.shape == (10, 1) and y.dtype == torch.complex64
+    assert rel_l2(host(y), g["y_forward"]) < T2[4]
+    assert rel_l2(host(y), nfft_ref.nfft_forward(g["x"], g["pos"], None, m=4)) < T1
+
+
+@pytest.mark.parametrize("m", [2, 4, 8])
+def test_golden_g3_1d(tn, m):
+    g = load_golden("g3_1d_n64")
+    ya = tn.nfft_adjoint(dev(g["x"]), dev(g["pos"]), None, bandwidth=64, cutoff=m)
+    assert ya.shape == (1, 64)
+    assert rel_l2(host(ya), g["y_adjoint"]) < T2[m]
+    assert rel_l2(host(ya), nfft_ref.nfft_adjoint(g["x"], g["pos"], None, N=64, m=m)) < T1
+    yf = tn.nfft_forward(dev(g["xhat"]), dev(g["pos"]), None, cutoff=m)
+    assert yf.shape == (1000,)
+    assert rel_l2(host(yf), g["y_forward"]) < T2[m]
+    assert rel_l2(host(yf), nfft_ref.nfft_forward(g["xhat"], g["pos"], None, m=m)) < T1
+
+
+def test_golden_g4_3d_ragged(tn):
+    g = load_golden("g4_3d_ragged")
+    pos, batch = dev(g["pos"]), dev(g["batch"])
+    for key in ("real", "complex"):
+        y = tn.nfft_adjoint(dev(g["x_" + key]), pos, batch, bandwidth=16, cutoff=4)
+        assert y.shape == (3, 16, 16, 16, 2)
+        assert rel_l2(host(y), g["y_adjoint_" + key]) < T2[4]
+        assert rel_l2(host(y), nfft_ref.nfft_adjoint(g["x_" + key], g["pos"], g["batch"], N=16, m=4)) < T1
+    yf = tn.nfft_forward(dev(g["xhat"]), pos, batch, cutoff=4)
+    assert yf.shape == (200, 2)
+    assert rel_l2(host(yf), g["y_forward"]) < T2[4]
+    assert rel_l2(host(yf), nfft_ref.nfft_forward(g["xhat"], g["pos"], g["batch"], m=4)) < T1
+
+
+def test_golden_g5_grad_shapes(tn):
+    g = load_golden("g5_grad_shapes")
+    pos, batch = dev(g["pos"]), dev(g["batch"])
+    ya = tn.nfft_adjoint(dev(g["x"]), pos, batch, bandwidth=16, cutoff=3)
+    assert rel_l2(host(ya), g["y_adjoint"]) < T2[3]
+    yf = tn.nfft_forward(dev(g["xhat"]), pos, batch, cutoff=3)
+    assert rel_l2(host(yf), g["y_forward"]) < T2[3]
+
+
+# ----------------------------------------------------------------------------- oracle sweeps
+
+def _random_problem(rng, d, n, B, cols, complex_x):
+    pos = (rng.random((n, d)) - 0.5).astype(np.float32)
+    if B > 1:
+        batch = np.sort(rng.integers(0, B, n)).astype(np.int64)
+        batch[0], batch[-1] = 0, B - 1
+    else:
+        batch = None
+    shape = (n,) + cols
+    x = rng.standard_normal(shape).astype(np.float32)
+    if complex_x:
+        x = (x + 1j * rng.standard_normal(shape)).astype(np.complex64)
+    return pos, batch, x
+
+
+@pytest.mark.parametrize("d,N,m", [(1, 64, 2), (1, 32, 3), (1, 512, 4), (2, 16, 3), (2, 32, 4), (2, 64, 2),
+                                   (3, 16, 4), (3, 16, 2), (3, 24, 3), (3, 32, 4), (2, 16, 6), (3, 16, 5),
+                                   (1, 64, 8), (2, 32, 8), (3, 20, 7), (2, 8, 1)])
+@pytest.mark.parametrize("complex_x", [False, True])
+def test_adjoint_and_forward_vs_oracle(tn, d, N, m, complex_x):
+    rng = np.random.default_rng(1000 * d + N + m)
+    n, B, cols = 700, 3, (2,)
+    pos, batch, x = _random_problem(rng, d, n, B, cols, complex_x)
+    ya = tn.nfft_adjoint(dev(x), dev(pos), dev(batch), bandwidth=N, cutoff=m)
+    assert ya.shape == (B,) + (N,) * d + cols and ya.dtype == torch.complex64
+    ref = nfft_ref.nfft_adjoint(x, pos, batch, N=N, m=m)
+    assert rel_l2(host(ya), ref) < T1
+    assert rel_l2(host(ya), ndft.ndft_adjoint(x, pos, batch, N=N)) < T2[m]
+    # forward of a random spectrum
+    xh = rng.standard_normal((B,) + (N,) * d + cols).astype(np.float32)
+    if complex_x:
+        xh = (xh + 1j * rng.standard_normal(xh.shape)).astype(np.complex64)
+    yf = tn.nfft_forward(dev(xh), dev(pos), dev(batch), cutoff=m)
+    assert yf.shape == (n,) + cols and yf.dtype == torch.complex64
+    assert rel_l2(host(yf), nfft_ref.nfft_forward(xh, pos, batch, m=m)) < T1
+    assert rel_l2(host(yf), ndft.ndft_forward(xh, pos, batch)) < T2[m]
+
+
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_real_output_variants(tn, d):
+    rng = np.random.default_rng(77 + d)
+    N, m, n = 16, 4, 300
+    pos, batch, x = _random_problem(rng, d, n, 2, (3,), True)
+    ya = tn.nfft_adjoint(dev(x), dev(pos), dev(batch), bandwidth=N, cutoff=m, real_output=True)
+    assert ya.dtype == torch.float32
+    assert rel_l2(host(ya), nfft_ref.nfft_adjoint(x, pos, batch, N=N, m=m, real_output=True)) < T1
+    xh = (rng.standard_normal((2,) + (N,) * d + (3,)) + 1j * rng.standard_normal((2,) + (N,) * d + (3,))).astype(np.complex64)
+    yf = tn.nfft_forward(dev(xh), dev(pos), dev(batch), cutoff=m, real_output=True)
+    assert yf.dtype == torch.float32 and yf.shape == (n, 3)
+    assert rel_l2(host(yf), nfft_ref.nfft_forward(xh, pos, batch, m=m, real_output=True)) < T1
+
+
+def test_trailing_shapes_and_no_columns(tn):
+    rng = np.random.default_rng(5)
+    pos, batch, x = _random_problem(rng, 2, 200, 1, (2, 3), False)
+    ya = tn.nfft_adjoint(dev(x), dev(pos), None, bandwidth=16, cutoff=3)
+    assert ya.shape == (1, 16, 16, 2, 3)
+    assert rel_l2(host(ya), nfft_ref.nfft_adjoint(x, pos, None, N=16, m=3)) < T1
+    x1 = x[:, 0, 0].copy()  # 1-D x: no trailing dimension
+    y1 = tn.nfft_adjoint(dev(x1), dev(pos), None, bandwidth=16, cutoff=3)
+    assert y1.shape == (1, 16, 16)
+    assert rel_l2(host(y1), host(ya)[..., 0, 0]) < 1e-5
+    yf = tn.nfft_forward(ya, dev(pos), None, cutoff=3)
+    assert yf.shape == (200, 2, 3)
+    assert rel_l2(host(yf), nfft_ref.nfft_forward(host(ya), pos, None, m=3)) < T1
+
+
+def test_edge_points_periodic_wrap(tn):
+    # torus boundary, exact grid nodes, the largest float below 1/2, and a point outside [-1/2,1/2)
+    pos = np.array([[-0.5, -0.5, -0.5], [0.49999997, 0.49999997, 0.49999997], [0.0, 0.0, 0.0],
+                    [-0.5, 0.25, 0.125], [0.25, -0.5, 0.49999997], [0.46875, -0.46875, 0.0],
+                    [0.75, -0.75, 1.25]], np.float32)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((7, 1)).astype(np.float32)
+    ya = tn.nfft_adjoint(dev(x), dev(pos), None, bandwidth=16, cutoff=4)
+    assert rel_l2(host(ya), ndft.ndft_adjoint(x, pos, None, N=16)) < T2[4]
+    yf = tn.nfft_forward(ya, dev(pos), None, cutoff=4)
+    assert rel_l2(host(yf), ndft.ndft_forward(host(ya), pos, None)) < T2[4]
+
+
+def test_empty_and_tiny_inputs(tn):
+    pos = torch.zeros((0, 2), dtype=torch.float32, device="cuda")
+    x = torch.zeros((0, 3), dtype=torch.float32, device="cuda")
+    y = tn.nfft_adjoint(x, pos, None, bandwidth=8, cutoff=2)
+    assert y.shape == (1, 8, 8, 3) and float(y.abs().max()) == 0.0
+    xh = torch.randn((1, 8, 8, 3), dtype=torch.complex64, device="cuda")
+    assert tn.nfft_forward(xh, pos, None, cutoff=2).shape == (0, 3)
+    # one point, empty point sets in the middle of the batch
+    pos1 = np.array([[0.1, -0.2]], np.float32)
+    ya = tn.nfft_adjoint(dev(np.ones((1,), np.float32)), dev(pos1), dev(np.array([2], np.int64)), bandwidth=8, cutoff=3)
+    assert ya.shape == (3, 8, 8)
+    assert float(ya[:2].abs().max()) == 0.0
+    assert rel_l2(host(ya[2:]), ndft.ndft_adjoint(np.ones((1,)), pos1, None, N=8)) < T2[3]
+
+
+def test_non_contiguous_inputs(tn):
+    rng = np.random.default_rng(21)
+    pos, _, x = _random_problem(rng, 2, 150, 1, (4,), False)
+    xd = dev(x)[:, ::2]  # non-contiguous view
+    posd = dev(np.concatenate([pos, pos], 1))[:, :2]
+    ya = tn.nfft_adjoint(xd, posd, None, bandwidth=16, cutoff=4)
+    assert rel_l2(host(ya), nfft_ref.nfft_adjoint(x[:, ::2], pos, None, N=16, m=4)) < T1
+
+
+def test_input_checks(tn):
+    pos = torch.zeros((4, 2), device="cuda")
+    x = torch.zeros((4,), device="cuda")
+    with pytest.raises(RuntimeError, match="Input mismatch"):
+        tn.nfft_adjoint(torch.zeros((5,), device="cuda"), pos)
+    with pytest.raises(RuntimeError, match="Input mismatch"):
+        tn.nfft_adjoint(x, torch.zeros((4, 4), device="cuda"))
+    with pytest.raises(RuntimeError, match="Input mismatch"):
+        tn.nfft_adjoint(x.double(), pos)
+    with pytest.raises(RuntimeError, match="Input mismatch"):
+        tn.nfft_adjoint(x, pos, cutoff=9)
+    with pytest.raises(RuntimeError, match="Input mismatch"):
+        tn.nfft_forward(torch.zeros((2, 8, 8), device="cuda"), pos)  # batch_size mismatch
+    with pytest.raises(RuntimeError, match="Input mismatch"):
+        tn.nfft_forward(torch.zeros((1, 8, 6), device="cuda"), pos)
+    with pytest.raises(RuntimeError, match="only implemented for GPU tensors"):
+        tn.nfft_adjoint(x.cpu(), pos.cpu())
+
+
+def test_operator_namespace(tn):
+    """torch.ops.torch_nfft.* keeps the reference's positional schema (csrc/core.cpp:176-184)."""
+    rng = np.random.default_rng(31)
+    pos, batch, x = _random_problem(rng, 2, 100, 2, (), False)
+    y1 = torch.ops.torch_nfft.nfft_adjoint(dev(pos), dev(x), dev(batch), 16, 3, 0)
+    y2 = tn.nfft_adjoint(dev(x), dev(pos), dev(batch), bandwidth=16, cutoff=3)
+    assert rel_l2(host(y1), host(y2)) < 1e-5
+    z1 = torch.ops.torch_nfft.nfft_forward(dev(pos), y1, dev(batch), 3, 1)
+    assert z1.dtype == torch.float32 and z1.shape == (100,)
+
+
+# ----------------------------------------------------------------------------- autograd (test_grad.py scenarios)
+
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_autograd_adjointness(tn, d):
+    """The reference's test_grad.py compares backward() with finite differences; for a linear operator that is
+    the statement <A x, y> = <x, A^H y>, checked here exactly (up to fp32) through autograd."""
+    rng = np.random.default_rng(41 + d)
+    N, m, n, B = 16, 3, 40, 2
+    pos, batch, x = _random_problem(rng, d, n, B, (3,), False)
+    xt = dev(x).requires_grad_(True)
+    ya = tn.nfft_adjoint(xt, dev(pos), dev(batch), bandwidth=N, cutoff=m)
+    w = torch.randn_like(ya)
+    loss = (ya * w.conj()).real.sum()
+    loss.backward()
+    # d/dx Re<A x, w> = Re(A^H w) where A^H = forward transform
+    expect = tn.nfft_forward(w, dev(pos), dev(batch), cutoff=m, real_output=True)
+    assert rel_l2(host(xt.grad), host(expect)) < 1e-5
+    assert rel_l2(host(xt.grad), nfft_ref.nfft_forward(host(w), pos, batch, m=m, real_output=True)) < T1
+    # forward op: gradient is the adjoint transform
+    xh = torch.randn((B,) + (N,) * d + (3,), dtype=torch.complex64, device="cuda", requires_grad=True)
+    yf = tn.nfft_forward(xh, dev(pos), dev(batch), cutoff=m)
+    v = torch.randn_like(yf)
+    (yf * v.conj()).real.sum().backward()
+    ref = nfft_ref.nfft_adjoint(host(v), pos, batch, N=N, m=m)
+    assert rel_l2(host(xh.grad), ref) < T1
+    # finite-difference spot check as in test_grad.py:25-46 (|op(x)|.sum())
+    x0 = dev(x)
+    f = lambda t: tn.nfft_adjoint(t, dev(pos), dev(batch), bandwidth=N, cutoff=m).abs().sum()
+    x0.requires_grad_(True)
+    f(x0).backward()
+    eps = 1e-2
+    i, c = 3, 1
+    xp = x0.detach().clone(); xp[i, c] += eps
+    xm = x0.detach().clone(); xm[i, c] -= eps
+    fd = (f(xp) - f(xm)).item() / (2 * eps)
+    assert abs(fd - x0.grad[i, c].item()) <= 2e-2 * max(1.0, abs(fd))
+
+
+# ----------------------------------------------------------------------------- stage level + chunking
+
+def test_spread_stage_matches_oracle(tn):
+    """nfft_hip_plan_points + nfft_hip_spread against the oracle's gridding (real planes)."""
+    import ctypes
+    from torch_nfft_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(51)
+    d, N, m, n, B, Cr = 3, 16, 4, 500, 2, 2
+    pos, batch, x = _random_problem(rng, d, n, B, (Cr,), False)
+    prob = _lib.Problem(d, n, Cr, B, N, m)
+    plan = torch.empty(lib.nfft_hip_plan_bytes(ctypes.byref(prob)), dtype=torch.uint8, device="cuda")
+    post, batcht, xt = dev(pos), dev(batch), dev(x)
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(lib.nfft_hip_plan_points(ctypes.byref(prob), p(post), p(batcht), p(plan), plan.numel(), s))
+    M = 2 * N
+    grid = torch.full((B * Cr,) + (M,) * d, float("nan"), device="cuda")
+    scratch = torch.empty(n * Cr, device="cuda")
+    _lib.check(lib.nfft_hip_spread(ctypes.byref(prob), p(plan), p(xt), Cr, p(grid), p(scratch), s))
+    ref = nfft_ref.spread(x, pos, batch, N, m).real.reshape((B * Cr,) + (M,) * d)
+    assert rel_l2(host(grid), ref) < T1
+    # gather back: interpolation of the oracle grid at the same points
+    yr = torch.empty((n, Cr), device="cuda")
+    gt = dev(ref.astype(np.float32))
+    _lib.check(lib.nfft_hip_interpolate(ctypes.byref(prob), p(plan), p(gt), Cr, p(yr), s))
+    shift, psi = nfft_ref.window_taps(pos, N, m)
+    exp = np.zeros((n, Cr))
+    import itertools
+    for ls in itertools.product(range(2 * m + 2), repeat=d):
+        w = np.ones(n)
+        idx = []
+        for a, l in enumerate(ls):
+            w = w * psi[:, a, l]
+            idx.append((shift[:, a] + l + M) % M)
+        for c in range(Cr):
+            exp[:, c] += w * ref[(batch * Cr + c,) + tuple(idx)]
+    assert rel_l2(host(yr), exp) < T1
+
+
+def test_chunked_planes_path(tn, monkeypatch):
+    """Force the (batch, column) plane chunking used for grids that exceed the chunk budget."""
+    rng = np.random.default_rng(61)
+    d, N, m = 2, 16, 3
+    pos, batch, x = _random_problem(rng, d, 300, 2, (3,), True)
+    # budget for ~2 planes of (real grid + half spectrum)
+    monkeypatch.setenv("NFFT_HIP_CHUNK_BYTES", str(2 * (32 * 32 * 4 + 32 * 17 * 8) + 8))
+    from torch_nfft_amd import ops
+    ops._ws_bytes_cache.clear()
+    ya = tn.nfft_adjoint(dev(x), dev(pos), dev(batch), bandwidth=N, cutoff=m)
+    assert rel_l2(host(ya), nfft_ref.nfft_adjoint(x, pos, batch, N=N, m=m)) < T1
+    yf = tn.nfft_forward(ya, dev(pos), dev(batch), cutoff=m)
+    assert rel_l2(host(yf), nfft_ref.nfft_forward(host(ya), pos, batch, m=m)) < T1
+    ops._ws_bytes_cache.clear()
+
+
+def test_clustered_points_many_per_tile(tn):
+    """All points inside one grid cell neighbourhood: stresses LDS accumulation order and the chunk sweep."""
+    rng = np.random.default_rng(71)
+    n = 5000
+    pos = (0.013 * rng.standard_normal((n, 3)) + np.array([0.31, -0.07, 0.49])).astype(np.float32)
+    x = rng.standard_normal((n,)).astype(np.float32)
+    ya = tn.nfft_adjoint(dev(x), dev(pos), None, bandwidth=32, cutoff=4)
+    sub = np.stack(np.meshgrid(*[np.arange(-4, 4)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    ex = ndft.ndft_adjoint_subset(x, pos, sub)[:, 0]
+    got = host(ya)[0][tuple((sub + 16).T)]
+    assert rel_l2(got, ex) < T2[4]

@@ -1,0 +1,93 @@
+"""Loader for the C-ABI library ``libnfft_hip.so`` (declared in ``include/nfft_hip.h``).
+
+The product path has no CPU fallback: if the HIP library is missing or lacks a symbol the
+import fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnfft_hip.so")
+
+ABI_VERSION = 1
+
+# every symbol include/nfft_hip.h declares
+SYMBOLS = (
+    "nfft_hip_abi_version",
+    "nfft_hip_last_error",
+    "nfft_hip_adjoint_workspace_bytes",
+    "nfft_hip_forward_workspace_bytes",
+    "nfft_hip_adjoint",
+    "nfft_hip_forward",
+    "nfft_hip_plan_bytes",
+    "nfft_hip_plan_points",
+    "nfft_hip_spread",
+    "nfft_hip_interpolate",
+)
+
+OK, EINVAL, EWORKSPACE, EFFT, EHIP = 0, 1, 2, 3, 4
+
+
+class Problem(ctypes.Structure):
+    """``nfft_hip_problem`` of include/nfft_hip.h."""
+    _fields_ = [
+        ("dim", ctypes.c_int32),
+        ("num_points", ctypes.c_int64),
+        ("num_columns", ctypes.c_int64),
+        ("batch_size", ctypes.c_int64),
+        ("N", ctypes.c_int64),
+        ("m", ctypes.c_int64),
+    ]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "torch_nfft_amd: %s is missing -- build it with `python -m torch_nfft_amd.build` "
+            "(there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name in SYMBOLS:
+        if not hasattr(lib, name):
+            raise ImportError("torch_nfft_amd: %s does not export %s" % (LIB_PATH, name))
+    P = ctypes.POINTER(Problem)
+    vp, i64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    lib.nfft_hip_abi_version.restype = ci
+    lib.nfft_hip_last_error.restype = ctypes.c_char_p
+    for f in (lib.nfft_hip_adjoint_workspace_bytes, lib.nfft_hip_forward_workspace_bytes):
+        f.argtypes = [P, ci, ci]
+        f.restype = i64
+    for f in (lib.nfft_hip_adjoint, lib.nfft_hip_forward):
+        f.argtypes = [P, vp, vp, ci, vp, ci, vp, vp, i64, vp]
+        f.restype = ci
+    lib.nfft_hip_plan_bytes.argtypes = [P]
+    lib.nfft_hip_plan_bytes.restype = i64
+    lib.nfft_hip_plan_points.argtypes = [P, vp, vp, vp, i64, vp]
+    lib.nfft_hip_plan_points.restype = ci
+    lib.nfft_hip_spread.argtypes = [P, vp, vp, i64, vp, vp, vp]
+    lib.nfft_hip_spread.restype = ci
+    lib.nfft_hip_interpolate.argtypes = [P, vp, vp, i64, vp, vp]
+    lib.nfft_hip_interpolate.restype = ci
+    if lib.nfft_hip_abi_version() != ABI_VERSION:
+        raise ImportError("torch_nfft_amd: ABI version mismatch in %s" % LIB_PATH)
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().nfft_hip_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    """Map a C-ABI return code onto the exceptions the reference raises (RuntimeError)."""
+    if rc == OK:
+        return
+    msg = last_error()
+    if rc == EINVAL and not msg.startswith("Input mismatch"):
+        msg = "Input mismatch: " + msg
+    raise RuntimeError(msg)

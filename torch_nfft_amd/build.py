@@ -1,0 +1,55 @@
+"""Builds torch_nfft_amd/libnfft_hip.so (the C-ABI library of include/nfft_hip.h) for gfx950.
+
+Plain hipcc, no torch headers: the library's ABI is C.  Sources are compiled in parallel and
+relinked only when something changed.  Usage: ``python -m torch_nfft_amd.build [--force]``.
+"""
+import concurrent.futures
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_obj")
+LIB = os.path.join(HERE, "libnfft_hip.so")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+HIPCC = os.path.join(ROCM, "bin", "hipcc")
+SOURCES = ["api.hip", "binning.hip", "spread.hip", "interp.hip", "spectral.hip", "fft.cpp"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast",
+         "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROCM, "include")]
+
+
+def _headers_mtime():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(os.path.dirname(HERE), "include", "nfft_hip.h"))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(src, force, hdr_mtime):
+    obj = os.path.join(OBJ, src + ".o")
+    path = os.path.join(CSRC, src)
+    if (not force and os.path.exists(obj)
+            and os.path.getmtime(obj) >= max(os.path.getmtime(path), hdr_mtime)):
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", path, "-o", obj]
+    subprocess.check_call(cmd)
+    return obj, True
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hdr = _headers_mtime()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        results = list(ex.map(lambda s: _compile(s, force, hdr), SOURCES))
+    objs = [r[0] for r in results]
+    if force or any(r[1] for r in results) or not os.path.exists(LIB):
+        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + \
+              ["-L" + os.path.join(ROCM, "lib"), "-lrocfft", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
+        subprocess.check_call(cmd)
+        if verbose:
+            print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,234 @@
+// C-ABI entry points (include/nfft_hip.h): validation, workspace carving and stage orchestration.
+//
+// Host drivers being replaced: nfft_adjoint_cuda (csrc/cuda/core_cuda.cu:144-336) and
+// nfft_forward_cuda (:340-531) of the reference, including its validators check_point_input (:38-66),
+// check_spatial_coeffs_input (:69-86), check_spectral_coeffs_input (:89-115) and
+// setup_spectral_dimensions (:118-137).  Differences in behaviour, all on the safe side:
+//   * nothing synchronises the device and nothing is allocated or freed here (the reference issues six
+//     cudaDeviceSynchronize and four cudaMalloc/cudaFree per call);
+//   * errors are returned (the reference calls exit() on a CUDA error, cuda_utils.cu:7-14);
+//   * the preconditions the reference only documents (1 <= m, 2m+2 <= 2N, N even) are checked.
+#include "../../include/nfft_hip.h"
+
+#include <cstdlib>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace nfft {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+namespace {
+
+int validate(const nfft_hip_problem *p)
+{
+    if (!p) { set_error("Input mismatch: null problem"); return NFFT_HIP_EINVAL; }
+    if (p->dim < 1 || p->dim > 3) { set_error("Input mismatch: dim must be 1, 2 or 3"); return NFFT_HIP_EINVAL; }
+    if (p->num_points < 0 || p->num_columns < 0 || p->batch_size < 1) {
+        set_error("Input mismatch: negative size");
+        return NFFT_HIP_EINVAL;
+    }
+    if (p->N < 2 || (p->N & 1)) { set_error("Input mismatch: bandwidth N must be even and >= 2"); return NFFT_HIP_EINVAL; }
+    if (p->m < 1 || p->m > kMaxCutoff) { set_error("Input mismatch: cutoff m must be in 1..8"); return NFFT_HIP_EINVAL; }
+    if (2 * p->m + 2 > 2 * p->N) { set_error("Input mismatch: window 2m+2 exceeds the oversampled grid 2N"); return NFFT_HIP_EINVAL; }
+    if (p->N > (1 << 20)) { set_error("Input mismatch: bandwidth too large"); return NFFT_HIP_EINVAL; }
+    if (p->num_points >= (int64_t(1) << 31)) { set_error("Input mismatch: too many points"); return NFFT_HIP_EINVAL; }
+    return 0;
+}
+
+int64_t grid_budget_bytes()
+{
+    // upper bound for (real grid + half spectrum) of one chunk of planes; the rest of the 288 GB stays free
+    // for the caller.  Overridable for tests of the chunked path.
+    const char *env = std::getenv("NFFT_HIP_CHUNK_BYTES");
+    if (env) {
+        const long long v = std::atoll(env);
+        if (v > 0) return (int64_t)v;
+    }
+    return int64_t(16) << 30;
+}
+
+struct Carve {
+    Geom g;
+    PlanLayout L;
+    int64_t n, B, C, Cr, total_planes, chunk_planes;
+    int64_t half_cells;
+    int64_t off_plan, off_xs, off_grid, off_spec, off_work, work_bytes, total;
+};
+
+// planes_per_col: 2 when a column owns a (re, im) pair of real planes, else 1
+int make_carve(const nfft_hip_problem *p, int planes_per_col, bool need_xs, FftKind kind, Carve &c)
+{
+    c.g = make_geom(p->dim, p->N, p->m);
+    c.n = p->num_points;
+    c.B = p->batch_size;
+    c.C = p->num_columns;
+    c.Cr = c.C * planes_per_col;
+    c.total_planes = c.B * c.Cr;
+    c.L = plan_layout(c.g, c.n, c.B);
+    c.half_cells = (int64_t)(c.g.M / 2 + 1);
+    for (int a = 0; a < 2; ++a) c.half_cells *= c.g.Ma[a];
+    const int64_t plane_bytes = c.g.cells * 4 + c.half_cells * 8;
+    int64_t chunk = grid_budget_bytes() / plane_bytes;
+    chunk -= chunk % planes_per_col;
+    if (chunk < planes_per_col) chunk = planes_per_col;
+    if (chunk > c.total_planes) chunk = c.total_planes;
+    if (chunk > 32768) chunk = 32768 - 32768 % planes_per_col;  // blockIdx.y limit
+    c.chunk_planes = chunk;
+    c.work_bytes = 0;
+    if (c.total_planes > 0) {
+        // plans for the full chunk and for the remainder chunk
+        int64_t w = fft_work_bytes(kind, c.g.dim, c.g.M, chunk);
+        if (w < 0) return NFFT_HIP_EFFT;
+        c.work_bytes = w;
+        const int64_t rem = c.total_planes % chunk;
+        if (rem) {
+            w = fft_work_bytes(kind, c.g.dim, c.g.M, rem);
+            if (w < 0) return NFFT_HIP_EFFT;
+            if (w > c.work_bytes) c.work_bytes = w;
+        }
+    }
+    int64_t o = 0;
+    c.off_plan = o; o = align_up(o + c.L.total, 256);
+    c.off_xs = o;   o = align_up(o + (need_xs ? c.n * c.Cr * 4 : 0), 256);
+    c.off_grid = o; o = align_up(o + chunk * c.g.cells * 4, 256);
+    c.off_spec = o; o = align_up(o + chunk * c.half_cells * 8, 256);
+    c.off_work = o; o = align_up(o + c.work_bytes, 256);
+    c.total = o + 256;
+    return 0;
+}
+
+} // namespace
+} // namespace nfft
+
+using namespace nfft;
+
+extern "C" {
+
+int nfft_hip_abi_version(void) { return NFFT_HIP_ABI_VERSION; }
+const char *nfft_hip_last_error(void) { return g_last_error.c_str(); }
+
+int64_t nfft_hip_adjoint_workspace_bytes(const nfft_hip_problem *p, int x_is_complex, int real_output)
+{
+    (void)real_output;
+    if (validate(p)) return -1;
+    Carve c;
+    if (make_carve(p, x_is_complex ? 2 : 1, true, kR2C, c)) return -1;
+    return c.total;
+}
+
+int64_t nfft_hip_forward_workspace_bytes(const nfft_hip_problem *p, int x_is_complex, int real_output)
+{
+    (void)x_is_complex;
+    if (validate(p)) return -1;
+    Carve c;
+    if (make_carve(p, real_output ? 1 : 2, false, kC2R, c)) return -1;
+    return c.total;
+}
+
+int64_t nfft_hip_plan_bytes(const nfft_hip_problem *p)
+{
+    if (validate(p)) return -1;
+    const Geom g = make_geom(p->dim, p->N, p->m);
+    return plan_layout(g, p->num_points, p->batch_size).total;
+}
+
+int nfft_hip_plan_points(const nfft_hip_problem *p, const float *pos, const int64_t *batch, void *plan,
+                         int64_t plan_bytes, void *stream)
+{
+    if (int rc = validate(p)) return rc;
+    const Geom g = make_geom(p->dim, p->N, p->m);
+    const PlanLayout L = plan_layout(g, p->num_points, p->batch_size);
+    if (!plan || plan_bytes < L.total) { set_error("plan buffer too small"); return NFFT_HIP_EWORKSPACE; }
+    if (p->num_points > 0 && !pos) { set_error("Input mismatch: pos is null"); return NFFT_HIP_EINVAL; }
+    return launch_plan_points(g, L, pos, batch, p->num_points, p->batch_size, plan, (hipStream_t)stream);
+}
+
+int nfft_hip_spread(const nfft_hip_problem *p, const void *plan, const float *xr, int64_t real_columns, float *grid,
+                    float *scratch, void *stream)
+{
+    if (int rc = validate(p)) return rc;
+    const Geom g = make_geom(p->dim, p->N, p->m);
+    const PlanLayout L = plan_layout(g, p->num_points, p->batch_size);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t planes = p->batch_size * real_columns;
+    if (planes > 32768) { set_error("Input mismatch: too many planes for one spread call"); return NFFT_HIP_EINVAL; }
+    if (int rc = launch_gather_rows(g, L, plan, p->num_points, xr, real_columns, scratch, s)) return rc;
+    NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(planes * g.cells * 4), s));
+    return launch_spread(g, L, plan, scratch, p->num_points, real_columns, 0, planes, grid, s);
+}
+
+int nfft_hip_interpolate(const nfft_hip_problem *p, const void *plan, const float *grid, int64_t real_columns,
+                         float *yr, void *stream)
+{
+    if (int rc = validate(p)) return rc;
+    const Geom g = make_geom(p->dim, p->N, p->m);
+    const PlanLayout L = plan_layout(g, p->num_points, p->batch_size);
+    const int64_t planes = p->batch_size * real_columns;
+    if (planes > 32768) { set_error("Input mismatch: too many planes for one interpolate call"); return NFFT_HIP_EINVAL; }
+    return launch_interp(g, L, plan, grid, p->num_points, real_columns, 0, planes, yr, (hipStream_t)stream);
+}
+
+int nfft_hip_adjoint(const nfft_hip_problem *p, const float *pos, const void *x, int x_is_complex,
+                     const int64_t *batch, int real_output, void *y, void *workspace, int64_t workspace_bytes,
+                     void *stream)
+{
+    if (int rc = validate(p)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int ppc = x_is_complex ? 2 : 1;
+    Carve c;
+    if (int rc = make_carve(p, ppc, true, kR2C, c)) return rc;
+    if (c.total_planes == 0) return 0;
+    if (!y) { set_error("Input mismatch: y is null"); return NFFT_HIP_EINVAL; }
+    if (c.n > 0 && (!pos || !x)) { set_error("Input mismatch: null input"); return NFFT_HIP_EINVAL; }
+    if (!workspace || workspace_bytes < c.total) { set_error("workspace too small"); return NFFT_HIP_EWORKSPACE; }
+    char *ws = (char *)(((uintptr_t)workspace + 255) & ~uintptr_t(255));
+    void *plan = ws + c.off_plan;
+    float *xs = (float *)(ws + c.off_xs);
+    float *grid = (float *)(ws + c.off_grid);
+    float2 *spec = (float2 *)(ws + c.off_spec);
+    void *work = ws + c.off_work;
+
+    if (int rc = launch_plan_points(c.g, c.L, pos, batch, c.n, c.B, plan, s)) return rc;
+    if (int rc = launch_gather_rows(c.g, c.L, plan, c.n, (const float *)x, c.Cr, xs, s)) return rc;
+    for (int64_t p0 = 0; p0 < c.total_planes; p0 += c.chunk_planes) {
+        const int64_t np = std::min(c.chunk_planes, c.total_planes - p0);
+        NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(np * c.g.cells * 4), s));
+        if (int rc = launch_spread(c.g, c.L, plan, xs, c.n, c.Cr, p0, np, grid, s)) return rc;
+        if (int rc = fft_execute(kR2C, c.g.dim, c.g.M, np, grid, spec, work, c.work_bytes, s)) return rc;
+        if (int rc = launch_deconv_adjoint(c.g, spec, c.C, x_is_complex, real_output, p0, np, y, s)) return rc;
+    }
+    return 0;
+}
+
+int nfft_hip_forward(const nfft_hip_problem *p, const float *pos, const void *xhat, int x_is_complex,
+                     const int64_t *batch, int real_output, void *y, void *workspace, int64_t workspace_bytes,
+                     void *stream)
+{
+    if (int rc = validate(p)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int ppc = real_output ? 1 : 2;
+    Carve c;
+    if (int rc = make_carve(p, ppc, false, kC2R, c)) return rc;
+    if (c.total_planes == 0 || c.n == 0) return 0;
+    if (!y || !pos || !xhat) { set_error("Input mismatch: null input"); return NFFT_HIP_EINVAL; }
+    if (!workspace || workspace_bytes < c.total) { set_error("workspace too small"); return NFFT_HIP_EWORKSPACE; }
+    char *ws = (char *)(((uintptr_t)workspace + 255) & ~uintptr_t(255));
+    void *plan = ws + c.off_plan;
+    float *grid = (float *)(ws + c.off_grid);
+    float2 *spec = (float2 *)(ws + c.off_spec);
+    void *work = ws + c.off_work;
+
+    if (int rc = launch_plan_points(c.g, c.L, pos, batch, c.n, c.B, plan, s)) return rc;
+    for (int64_t p0 = 0; p0 < c.total_planes; p0 += c.chunk_planes) {
+        const int64_t np = std::min(c.chunk_planes, c.total_planes - p0);
+        if (int rc = launch_deconv_forward(c.g, xhat, c.C, x_is_complex, real_output, p0, np, spec, s)) return rc;
+        if (int rc = fft_execute(kC2R, c.g.dim, c.g.M, np, spec, grid, work, c.work_bytes, s)) return rc;
+        if (int rc = launch_interp(c.g, c.L, plan, grid, c.n, c.Cr, p0, np, (float *)y, s)) return rc;
+    }
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,151 @@
+// Shared host/device definitions of the MI355X NFFT hot path (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+namespace nfft {
+
+// ---- error plumbing -------------------------------------------------------
+void set_error(const std::string &msg);
+#define NFFT_HIP_CHECK(expr)                                                                      \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            nfft::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+            return 4; /* NFFT_HIP_EHIP */                                                         \
+        }                                                                                         \
+    } while (0)
+
+// ---- tiling of the oversampled grid --------------------------------------
+// Internally every problem is 3-D with axes (a0, a1, a2); a2 is the fastest
+// (last) axis of the grid.  For dim < 3 the leading axes are degenerate
+// (extent 1, one tap of weight 1).  User axis u maps to internal axis u + 3 - dim.
+//
+// A "pencil" is a T1 x T2 cross-section in (a1, a2) swept along a0 in chunks of
+// TC planes; (pencil, chunk) is the binning tile.  One workgroup sweeps a
+// segment of SEG chunks of one pencil.
+struct TileCfg {
+    int T1, T2; // pencil cross-section (axis 1, axis 2)
+    int R;      // planes in the LDS ring (power of two)
+    int TC;     // planes per chunk along axis 0: R - (W - 1), so a chunk's taps fit the ring
+};
+constexpr TileCfg tile_cfg(int dim, int W)
+{
+    return dim == 3 ? (W <= 14 ? TileCfg{32, 32, 16, 16 - (W - 1)} : TileCfg{16, 16, 32, 32 - (W - 1)})
+         : dim == 2 ? TileCfg{32, 32, 1, 1}
+                    : TileCfg{1, 256, 1, 1};
+}
+constexpr int kSegChunks = 8;   // chunks swept by one workgroup
+constexpr int kMaxW = 18;       // 2m+2 for m <= 8
+constexpr int kMaxCutoff = 8;
+
+struct Geom {
+    int dim;      // user dimension 1..3
+    int M;        // oversampled grid size per axis, 2N
+    int N;
+    int m;        // cutoff
+    int W;        // taps per axis, 2m+2
+    int Ma[3];    // extent per internal axis (1 when degenerate)
+    int Wa[3];    // taps per internal axis (1 when degenerate)
+    int Ta[3];    // tile extent per internal axis (Ta[0] = planes per chunk)
+    int nta[3];   // tiles per internal axis
+    int nseg;     // segments per pencil
+    int tiles_per_batch;
+    int64_t cells; // M^dim
+};
+
+inline Geom make_geom(int dim, int64_t N, int64_t m)
+{
+    Geom g;
+    g.dim = dim;
+    g.N = (int)N;
+    g.M = (int)(2 * N);
+    g.m = (int)m;
+    g.W = (int)(2 * m + 2);
+    g.cells = 1;
+    for (int a = 0; a < 3; ++a) {
+        const bool live = a >= 3 - dim;
+        g.Ma[a] = live ? g.M : 1;
+        g.Wa[a] = live ? g.W : 1;
+        if (live) g.cells *= g.M;
+    }
+    const TileCfg tc = tile_cfg(dim, g.W);
+    g.Ta[0] = tc.TC;
+    g.Ta[1] = tc.T1;
+    g.Ta[2] = tc.T2;
+    for (int a = 0; a < 3; ++a) {
+        if (g.Ta[a] > g.Ma[a]) g.Ta[a] = g.Ma[a];
+        g.nta[a] = (g.Ma[a] + g.Ta[a] - 1) / g.Ta[a];
+    }
+    g.nseg = (g.nta[0] + kSegChunks - 1) / kSegChunks;
+    g.tiles_per_batch = g.nta[0] * g.nta[1] * g.nta[2];
+    return g;
+}
+
+// ---- device helpers --------------------------------------------------------
+#if defined(__HIPCC__)
+
+// Window constants of the reference (Gaussian, oversampling 2):
+//   phi(t) = exp(-t^2 * (3 pi / 4) / m) * sqrt(0.75 / m)
+// (csrc/cuda/spatial_window_operations.cu:1-28).  We evaluate exp2 on the
+// pre-scaled exponent.
+__device__ __forceinline__ float win_exp_scale(int m)
+{
+    return -(2.356194490192345f / (float)m) * 1.4426950408889634f; // -(3pi/4)/m * log2(e)
+}
+__device__ __forceinline__ float win_norm(int m) { return sqrtf(0.75f / (float)m); }
+
+// Split pos*M into its integer cell in [0, M) and the fractional offset in [0, 1).
+// The reference computes shift = floor(pos*M) - m in fp32 (spatial_window_operations.cu:50) and
+// evaluates the window at pos*2N - shift - l formed in double (":85", the 2.0 literal), i.e. at the
+// exactly rounded offset.  pos*M is exact in fp32 for power-of-two M; for other M the fma residual
+// recovers the bits the fp32 product drops.
+__device__ __forceinline__ void split_cell(float pos, int M, int &cell, float &frac)
+{
+    const float Mf = (float)M;
+    const float hi = pos * Mf;
+    const float lo = fmaf(pos, Mf, -hi);
+    float fl = floorf(hi);
+    float fr = (hi - fl) + lo;
+    if (fr < 0.0f) { fr += 1.0f; fl -= 1.0f; }
+    if (fr >= 1.0f) { fr -= 1.0f; fl += 1.0f; }
+    if (!(fr >= 0.0f && fr < 1.0f)) fr = 0.0f;  // NaN / inf input: keep indices in range
+    // reduce the (possibly huge) integer part before converting
+    float q = fl - floorf(fl / Mf) * Mf;
+    int c = (int)q;
+    c %= M;
+    if (c < 0) c += M;
+    cell = c;
+    frac = fr;
+}
+
+__device__ __forceinline__ int wrap(int v, int M)
+{
+    v %= M;
+    return v < 0 ? v + M : v;
+}
+
+// Tile index of a point inside its batch: ((j1 * nt2 + j2) * nt0 + k0); chunks of one pencil are contiguous.
+__device__ __forceinline__ int tile_of_cells(const Geom &g, const int cell[3])
+{
+    const int k0 = cell[0] / g.Ta[0];
+    const int j1 = cell[1] / g.Ta[1];
+    const int j2 = cell[2] / g.Ta[2];
+    return (j1 * g.nta[2] + j2) * g.nta[0] + k0;
+}
+
+#endif // __HIPCC__
+
+// ---- plan layout -----------------------------------------------------------
+// [ tile_offset int32[ntiles+1] | cursor int32[ntiles] | perm int32[n] | spos float[n*dim] | scan temp ]
+struct PlanLayout {
+    int64_t ntiles;
+    int64_t off_offsets, off_cursor, off_perm, off_spos, off_scan, scan_bytes;
+    int64_t total;
+};
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B);
+
+} // namespace nfft

@@ -1,0 +1,115 @@
+// rocFFT plan cache + execution on the caller's stream.
+//
+// Replaces the reference's per-call cufftPlanMany / cufftExecC2C / cufftDestroy
+// (csrc/cuda/core_cuda.cu:254-272, 432-450).  The reference transforms a complex (2N)^d grid per
+// (batch, column); here every grid plane is real, so the adjoint uses a real-to-complex transform and
+// the forward a complex-to-real one (half the data and work), batched over the planes of a chunk.
+// Plans are created once per (kind, dim, M, batch, device) and kept; execution is bound to the
+// caller's stream (the reference leaves cuFFT on the default stream and synchronises the device).
+#include <rocfft/rocfft.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+
+#include "kernels.h"
+
+namespace nfft {
+
+namespace {
+struct PlanEntry {
+    rocfft_plan plan = nullptr;
+    size_t work_bytes = 0;
+};
+std::mutex g_mutex;
+bool g_setup = false;
+std::map<std::tuple<int, int, int, int, int64_t>, PlanEntry> g_plans;
+
+const char *status_name(rocfft_status s)
+{
+    switch (s) {
+    case rocfft_status_success: return "success";
+    case rocfft_status_failure: return "failure";
+    case rocfft_status_invalid_arg_value: return "invalid_arg_value";
+    case rocfft_status_invalid_dimensions: return "invalid_dimensions";
+    case rocfft_status_invalid_array_type: return "invalid_array_type";
+    case rocfft_status_invalid_strides: return "invalid_strides";
+    case rocfft_status_invalid_distance: return "invalid_distance";
+    case rocfft_status_invalid_offset: return "invalid_offset";
+    case rocfft_status_invalid_work_buffer: return "invalid_work_buffer";
+    default: return "unknown";
+    }
+}
+
+int get_plan(FftKind kind, int dim, int M, int64_t nplanes, PlanEntry &out)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        set_error("hipGetDevice failed");
+        return 4;
+    }
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (!g_setup) {
+        rocfft_setup();
+        g_setup = true;
+    }
+    const auto key = std::make_tuple(dev, (int)kind, dim, M, nplanes);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) {
+        out = it->second;
+        return 0;
+    }
+    size_t lengths[3] = {(size_t)M, (size_t)M, (size_t)M};
+    PlanEntry e;
+    rocfft_status st = rocfft_plan_create(&e.plan, rocfft_placement_notinplace,
+                                          kind == kR2C ? rocfft_transform_type_real_forward
+                                                       : rocfft_transform_type_real_inverse,
+                                          rocfft_precision_single, (size_t)dim, lengths, (size_t)nplanes, nullptr);
+    if (st != rocfft_status_success) {
+        set_error(std::string("Failed to create rocFFT plan: ") + status_name(st));
+        return 3;
+    }
+    st = rocfft_plan_get_work_buffer_size(e.plan, &e.work_bytes);
+    if (st != rocfft_status_success) {
+        set_error(std::string("rocfft_plan_get_work_buffer_size: ") + status_name(st));
+        return 3;
+    }
+    g_plans[key] = e;
+    out = e;
+    return 0;
+}
+} // namespace
+
+int64_t fft_work_bytes(FftKind kind, int dim, int M, int64_t nplanes)
+{
+    PlanEntry e;
+    if (get_plan(kind, dim, M, nplanes, e)) return -1;
+    return (int64_t)e.work_bytes;
+}
+
+int fft_execute(FftKind kind, int dim, int M, int64_t nplanes, void *in, void *out, void *work, int64_t work_bytes,
+                hipStream_t stream)
+{
+    PlanEntry e;
+    if (int rc = get_plan(kind, dim, M, nplanes, e)) return rc;
+    if ((int64_t)e.work_bytes > work_bytes) {
+        set_error("rocFFT work buffer too small");
+        return 2;
+    }
+    rocfft_execution_info info = nullptr;
+    rocfft_status st = rocfft_execution_info_create(&info);
+    if (st == rocfft_status_success) st = rocfft_execution_info_set_stream(info, stream);
+    if (st == rocfft_status_success && e.work_bytes)
+        st = rocfft_execution_info_set_work_buffer(info, work, e.work_bytes);
+    void *ins[1] = {in};
+    void *outs[1] = {out};
+    if (st == rocfft_status_success) st = rocfft_execute(e.plan, ins, outs, info);
+    if (info) rocfft_execution_info_destroy(info);
+    if (st != rocfft_status_success) {
+        set_error(std::string("Failed to execute rocFFT plan: ") + status_name(st));
+        return 3;
+    }
+    return 0;
+}
+
+} // namespace nfft

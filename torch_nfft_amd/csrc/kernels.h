@@ -1,0 +1,36 @@
+// Internal launch interface between the C-ABI layer (api.hip) and the kernel files.
+#pragma once
+#include "common.h"
+
+namespace nfft {
+
+// binning.hip
+int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, const int64_t *batch, int64_t n, int64_t B,
+                       void *plan, hipStream_t stream);
+// xs[c * n + slot] = xr[perm[slot] * cols + c]
+int launch_gather_rows(const Geom &g, const PlanLayout &L, const void *plan, int64_t n, const float *xr, int64_t cols,
+                       float *xs, hipStream_t stream);
+
+// spread.hip: grid[p, :] += ... for local planes p in [0, nplanes); global plane plane0 + p = b * Cr + cr
+int launch_spread(const Geom &g, const PlanLayout &L, const void *plan, const float *xs, int64_t n, int64_t Cr,
+                  int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream);
+
+// interp.hip: yr[perm[slot] * Cr + cr] = sum over taps of grid[p, ...]
+int launch_interp(const Geom &g, const PlanLayout &L, const void *plan, const float *grid, int64_t n, int64_t Cr,
+                  int64_t plane0, int64_t nplanes, float *yr, hipStream_t stream);
+
+// spectral.hip
+// adjoint roll-off: spec = R2C(grid) per real plane [nplanes, M^(d-1) * (M/2+1)] complex -> y [B, N^d, C]
+int launch_deconv_adjoint(const Geom &g, const float2 *spec, int64_t C, int x_is_complex, int real_output,
+                          int64_t plane0, int64_t nplanes, void *y, hipStream_t stream);
+// forward roll-off: xhat [B, N^d, C] -> Hermitian half-spectra of the real planes of g
+int launch_deconv_forward(const Geom &g, const void *xhat, int64_t C, int x_is_complex, int real_output,
+                          int64_t plane0, int64_t nplanes, float2 *spec, hipStream_t stream);
+
+// fft.cpp (rocFFT, plans cached per (kind, dim, M, batch) and device)
+enum FftKind { kR2C = 0, kC2R = 1 };
+int64_t fft_work_bytes(FftKind kind, int dim, int M, int64_t nplanes);
+int fft_execute(FftKind kind, int dim, int M, int64_t nplanes, void *in, void *out, void *work, int64_t work_bytes,
+                hipStream_t stream);
+
+} // namespace nfft
