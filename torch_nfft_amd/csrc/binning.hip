@@ -62,14 +62,14 @@ __global__ void __launch_bounds__(256) bin_fill_kernel(Geom g, const float *__re
     }
 }
 
-// xs[slot, :] = xr[perm[slot], :]  (tile-ordered copy of the real coefficient columns)
+// xs[c, slot] = xr[perm[slot], c]  (tile-ordered, column-major copy of the real coefficient columns)
 __global__ void __launch_bounds__(256) gather_rows_kernel(const int *__restrict__ perm, const float *__restrict__ xr,
                                                          float *__restrict__ xs, int64_t n, int64_t cols)
 {
     const int64_t total = n * cols;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t slot = e / cols, c = e - slot * cols;
-        xs[e] = xr[(int64_t)perm[slot] * cols + c];
+        xs[c * n + slot] = xr[(int64_t)perm[slot] * cols + c];
     }
 }
 
