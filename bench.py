@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Benchmark of the NFFT hot path on MI355X (contract: see the task's bench.py section).
+
+Workload (BASELINE.json metric "Mpoints/s (adjoint+forward, 3-D N=256 m=4)"): config C3 -- d=3, N=256,
+m=4, n=10^7 uniform points, one point set, real fp32 coefficients.  One "step" = nfft_adjoint(x) followed
+by nfft_forward(of that spectrum, real_output=True), i.e. one pass of the hot path in each direction over
+one batch of synthetic input, inputs resident in HBM.  value = n_gpus * n / t_step / 1e6.
+
+N > 1 GPUs (launched by torch.distributed.run): every rank runs the same-sized workload on its own point
+set (the batch axis is the sharding axis of this path; a single point set cannot be split without a
+distributed FFT), no data-path collective, "scaling": "weak".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_FMA_PER_S = 78.65e12      # 157.3 TFLOP/s fp32 vector = 78.65e12 FMA/s
+LDS_ATOMIC_PER_S = 256 * 16 * 2.4e9  # ds_add_f32 at the ds_write_b32 rate: 16 lanes/clk/CU
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--points", type=int, default=10_000_000)
+    ap.add_argument("--bandwidth", type=int, default=256)
+    ap.add_argument("--cutoff", type=int, default=4)
+    ap.add_argument("--dim", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(dim, N, target_s):
+    """Oracle (this repo's restatement of torch_nfft/ndft.py, plain C + OpenMP) timed on the host cores on a
+    bounded sample of the same workload: all N^dim frequencies, n' points (cost is linear in n')."""
+    from oracle import ndft_cpu
+    cores = ndft_cpu.max_threads()
+    rng = np.random.default_rng(20240)
+
+    def run(npts):
+        pos = (rng.random((npts, dim)) - 0.5).astype(np.float32)
+        x = rng.random((npts, 1))
+        t0 = time.perf_counter()
+        y = ndft_cpu.ndft_adjoint(x, pos, None, N=N)
+        t1 = time.perf_counter()
+        ndft_cpu.ndft_forward(y, pos, None)
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1
+
+    ta, tf = run(64)  # calibration
+    per_point = (ta + tf) / 64
+    npts = int(max(64, min(1_000_000, target_s / max(per_point, 1e-9))))
+    ta, tf = run(npts)
+    return {
+        "value": npts / (ta + tf) / 1e6,
+        "unit": "Mpoints/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "exact NDFT adjoint+forward (oracle/ndft_c.c, float64, OpenMP), all %d^%d frequencies, %d points: "
+                  "adjoint %.2f s + forward %.2f s" % (N, dim, npts, ta, tf),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    n_gpus = world
+
+    import torch_nfft_amd as tn
+    from torch_nfft_amd import _lib
+
+    d, N, m, n = args.dim, args.bandwidth, args.cutoff, args.points
+    M = 2 * N
+    gen = torch.Generator(device=dev).manual_seed(20240 + rank)
+    pos = torch.rand((n, d), generator=gen, device=dev) - 0.5
+    x = torch.rand((n,), generator=gen, device=dev)
+
+    def step():
+        y = tn.nfft_adjoint(x, pos, None, bandwidth=N, cutoff=m)
+        return tn.nfft_forward(y, pos, None, cutoff=m, real_output=True)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    _lib.profile_enable(True)
+    _lib.profile_collect()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stages = _lib.profile_collect()
+    _lib.profile_enable(False)
+
+    if distributed:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = n_gpus * n / (elapsed / args.steps) / 1e6
+        # dominant kernel: the spreading kernel (stage "spread" = exactly one launch of spread_kernel<3,10>)
+        sp_ms, sp_cnt = stages["spread"]
+        sp_avg = sp_ms / max(sp_cnt, 1)
+        alg_bytes = n * (4 * d + 4) + (M ** d) * 4  # every point read once, real grid written once
+        achieved = alg_bytes / (sp_avg * 1e-3) / 1e9 if sp_avg > 0 else 0.0
+        taps = n * (2 * m + 2) ** d
+        per_stage = {k: (v[0] / max(v[1], 1)) for k, v in stages.items() if v[1]}
+        # both transforms run the point plan and an FFT: split by launch count for the report
+        out = {
+            "metric": "Mpoints/s (adjoint+forward, 3-D N=256 m=4)",
+            "value": value,
+            "unit": "Mpoints/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "C3: %d-D adjoint+forward, N=%d, m=%d, %d uniform points per GPU, batch_size=1 per GPU, "
+                            "real fp32 x, forward with real_output" % (d, N, m, n),
+                "points_per_gpu": n, "bandwidth": N, "cutoff": m, "dim": d,
+                "parallelism": "batch-sharded x%d (one point set per GPU, no collective)" % n_gpus,
+            },
+            "roofline": {
+                "kernel": "spread_kernel<%d,%d>" % (d, 2 * m + 2),
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": sp_avg,
+                "launches": sp_cnt,
+                "taps_per_s": taps / (sp_avg * 1e-3) if sp_avg > 0 else 0.0,
+                "frac_of_valu_fma_peak": (taps / (sp_avg * 1e-3)) / VALU_FMA_PER_S if sp_avg > 0 else 0.0,
+                "frac_of_lds_atomic_rate": (taps / (sp_avg * 1e-3)) / LDS_ATOMIC_PER_S if sp_avg > 0 else 0.0,
+            },
+            "stage_ms_per_launch": per_stage,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(d, N, args.cpu_seconds)
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

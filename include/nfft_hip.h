@@ -106,6 +106,16 @@ int nfft_hip_spread(const nfft_hip_problem *p, const void *plan, const float *xr
 int nfft_hip_interpolate(const nfft_hip_problem *p, const void *plan, const float *grid,
                          int64_t real_columns, float *yr, void *stream);
 
+/* ---- measurement hooks (bench.py) ----
+ * When enabled, nfft_hip_adjoint / nfft_hip_forward bracket each stage with HIP events recorded on the
+ * caller's stream.  nfft_hip_profile_collect waits for the recorded events and returns, per stage, the
+ * summed GPU time in milliseconds and the number of launches since the last collect.  Stage order:
+ * 0 point plan (binning), 1 coefficient gather, 2 grid zero-fill, 3 spreading, 4 FFT, 5 roll-off, 6 interpolation.
+ * The reference has no counterpart (it has no timers at all). */
+#define NFFT_HIP_NUM_STAGES 7
+void nfft_hip_profile_enable(int enable);
+int nfft_hip_profile_collect(double *ms_per_stage, int64_t *launches_per_stage, int num_stages);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,10 @@ SYMBOLS = (
     "nfft_hip_plan_points",
     "nfft_hip_spread",
     "nfft_hip_interpolate",
+    "nfft_hip_profile_enable",
+    "nfft_hip_profile_collect",
 )
+STAGES = ("plan", "gather", "zero", "spread", "fft", "rolloff", "interp")
 
 OK, EINVAL, EWORKSPACE, EFFT, EHIP = 0, 1, 2, 3, 4
 
@@ -49,7 +52,7 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError(
-            "torch_nfft_amd: %s is missing -- build it with `python -m torch_nfft_amd.build` "
+            "torch_nfft_amd: %s is missing -- build it with `python torch_nfft_amd/build.py` "
             "(there is no CPU fallback)" % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
     for name in SYMBOLS:
@@ -73,10 +76,27 @@ def load():
     lib.nfft_hip_spread.restype = ci
     lib.nfft_hip_interpolate.argtypes = [P, vp, vp, i64, vp, vp]
     lib.nfft_hip_interpolate.restype = ci
+    lib.nfft_hip_profile_enable.argtypes = [ci]
+    lib.nfft_hip_profile_enable.restype = None
+    lib.nfft_hip_profile_collect.argtypes = [vp, vp, ci]
+    lib.nfft_hip_profile_collect.restype = ci
     if lib.nfft_hip_abi_version() != ABI_VERSION:
         raise ImportError("torch_nfft_amd: ABI version mismatch in %s" % LIB_PATH)
     _lib = lib
     return lib
+
+
+def profile_enable(on):
+    load().nfft_hip_profile_enable(1 if on else 0)
+
+
+def profile_collect():
+    """{stage: (total_ms, launches)} since the last collect (waits for the recorded events)."""
+    n = len(STAGES)
+    ms = (ctypes.c_double * n)()
+    cnt = (ctypes.c_int64 * n)()
+    check(load().nfft_hip_profile_collect(ms, cnt, n))
+    return {STAGES[i]: (float(ms[i]), int(cnt[i])) for i in range(n)}
 
 
 def last_error():

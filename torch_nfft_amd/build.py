@@ -1,7 +1,8 @@
 """Builds torch_nfft_amd/libnfft_hip.so (the C-ABI library of include/nfft_hip.h) for gfx950.
 
 Plain hipcc, no torch headers: the library's ABI is C.  Sources are compiled in parallel and
-relinked only when something changed.  Usage: ``python -m torch_nfft_amd.build [--force]``.
+relinked only when something changed.  Usage: ``python torch_nfft_amd/build.py [--force]`` (run as a
+script so that a stale or missing library cannot block its own rebuild through the package import).
 """
 import concurrent.futures
 import os

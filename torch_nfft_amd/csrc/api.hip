@@ -11,6 +11,7 @@
 #include "../../include/nfft_hip.h"
 
 #include <cstdlib>
+#include <vector>
 
 #include "common.h"
 #include "kernels.h"
@@ -19,6 +20,34 @@ namespace nfft {
 
 static thread_local std::string g_last_error;
 void set_error(const std::string &msg) { g_last_error = msg; }
+
+// ---- optional stage timing -------------------------------------------------------------------
+namespace {
+struct TimedSpan { int stage; hipEvent_t start, stop; };
+bool g_profile = false;
+std::vector<TimedSpan> g_spans;
+std::vector<hipEvent_t> g_free_events;
+hipEvent_t get_event()
+{
+    if (!g_free_events.empty()) { hipEvent_t e = g_free_events.back(); g_free_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+} // namespace
+
+StageTimer::StageTimer(Stage stage, hipStream_t s) : slot(-1), stream(s)
+{
+    if (!g_profile) return;
+    TimedSpan sp{(int)stage, get_event(), get_event()};
+    (void)hipEventRecord(sp.start, stream);
+    slot = (int)g_spans.size();
+    g_spans.push_back(sp);
+}
+StageTimer::~StageTimer()
+{
+    if (slot >= 0) (void)hipEventRecord(g_spans[slot].stop, stream);
+}
 
 namespace {
 
@@ -110,6 +139,26 @@ extern "C" {
 int nfft_hip_abi_version(void) { return NFFT_HIP_ABI_VERSION; }
 const char *nfft_hip_last_error(void) { return g_last_error.c_str(); }
 
+void nfft_hip_profile_enable(int enable)
+{
+    g_profile = enable != 0;
+}
+
+int nfft_hip_profile_collect(double *ms_per_stage, int64_t *launches_per_stage, int num_stages)
+{
+    for (int i = 0; i < num_stages; ++i) { ms_per_stage[i] = 0.0; launches_per_stage[i] = 0; }
+    for (const TimedSpan &sp : g_spans) {
+        float ms = 0.f;
+        NFFT_HIP_CHECK(hipEventSynchronize(sp.stop));
+        NFFT_HIP_CHECK(hipEventElapsedTime(&ms, sp.start, sp.stop));
+        if (sp.stage < num_stages) { ms_per_stage[sp.stage] += ms; launches_per_stage[sp.stage] += 1; }
+        g_free_events.push_back(sp.start);
+        g_free_events.push_back(sp.stop);
+    }
+    g_spans.clear();
+    return 0;
+}
+
 int64_t nfft_hip_adjoint_workspace_bytes(const nfft_hip_problem *p, int x_is_complex, int real_output)
 {
     (void)real_output;
@@ -191,14 +240,14 @@ int nfft_hip_adjoint(const nfft_hip_problem *p, const float *pos, const void *x,
     float2 *spec = (float2 *)(ws + c.off_spec);
     void *work = ws + c.off_work;
 
-    if (int rc = launch_plan_points(c.g, c.L, pos, batch, c.n, c.B, plan, s)) return rc;
-    if (int rc = launch_gather_rows(c.g, c.L, plan, c.n, (const float *)x, c.Cr, xs, s)) return rc;
+    { StageTimer t(kStagePlan, s); if (int rc = launch_plan_points(c.g, c.L, pos, batch, c.n, c.B, plan, s)) return rc; }
+    { StageTimer t(kStageGather, s); if (int rc = launch_gather_rows(c.g, c.L, plan, c.n, (const float *)x, c.Cr, xs, s)) return rc; }
     for (int64_t p0 = 0; p0 < c.total_planes; p0 += c.chunk_planes) {
         const int64_t np = std::min(c.chunk_planes, c.total_planes - p0);
-        NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(np * c.g.cells * 4), s));
-        if (int rc = launch_spread(c.g, c.L, plan, xs, c.n, c.Cr, p0, np, grid, s)) return rc;
-        if (int rc = fft_execute(kR2C, c.g.dim, c.g.M, np, grid, spec, work, c.work_bytes, s)) return rc;
-        if (int rc = launch_deconv_adjoint(c.g, spec, c.C, x_is_complex, real_output, p0, np, y, s)) return rc;
+        { StageTimer t(kStageZero, s); NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(np * c.g.cells * 4), s)); }
+        { StageTimer t(kStageSpread, s); if (int rc = launch_spread(c.g, c.L, plan, xs, c.n, c.Cr, p0, np, grid, s)) return rc; }
+        { StageTimer t(kStageFft, s); if (int rc = fft_execute(kR2C, c.g.dim, c.g.M, np, grid, spec, work, c.work_bytes, s)) return rc; }
+        { StageTimer t(kStageDeconv, s); if (int rc = launch_deconv_adjoint(c.g, spec, c.C, x_is_complex, real_output, p0, np, y, s)) return rc; }
     }
     return 0;
 }
@@ -221,12 +270,12 @@ int nfft_hip_forward(const nfft_hip_problem *p, const float *pos, const void *xh
     float2 *spec = (float2 *)(ws + c.off_spec);
     void *work = ws + c.off_work;
 
-    if (int rc = launch_plan_points(c.g, c.L, pos, batch, c.n, c.B, plan, s)) return rc;
+    { StageTimer t(kStagePlan, s); if (int rc = launch_plan_points(c.g, c.L, pos, batch, c.n, c.B, plan, s)) return rc; }
     for (int64_t p0 = 0; p0 < c.total_planes; p0 += c.chunk_planes) {
         const int64_t np = std::min(c.chunk_planes, c.total_planes - p0);
-        if (int rc = launch_deconv_forward(c.g, xhat, c.C, x_is_complex, real_output, p0, np, spec, s)) return rc;
-        if (int rc = fft_execute(kC2R, c.g.dim, c.g.M, np, spec, grid, work, c.work_bytes, s)) return rc;
-        if (int rc = launch_interp(c.g, c.L, plan, grid, c.n, c.Cr, p0, np, (float *)y, s)) return rc;
+        { StageTimer t(kStageDeconv, s); if (int rc = launch_deconv_forward(c.g, xhat, c.C, x_is_complex, real_output, p0, np, spec, s)) return rc; }
+        { StageTimer t(kStageFft, s); if (int rc = fft_execute(kC2R, c.g.dim, c.g.M, np, spec, grid, work, c.work_bytes, s)) return rc; }
+        { StageTimer t(kStageInterp, s); if (int rc = launch_interp(c.g, c.L, plan, grid, c.n, c.Cr, p0, np, (float *)y, s)) return rc; }
     }
     return 0;
 }

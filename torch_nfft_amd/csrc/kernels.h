@@ -33,4 +33,13 @@ int64_t fft_work_bytes(FftKind kind, int dim, int M, int64_t nplanes);
 int fft_execute(FftKind kind, int dim, int M, int64_t nplanes, void *in, void *out, void *work, int64_t work_bytes,
                 hipStream_t stream);
 
+// api.hip: optional per-stage GPU timing with HIP events on the caller's stream (nfft_hip_profile_*)
+enum Stage { kStagePlan = 0, kStageGather, kStageZero, kStageSpread, kStageFft, kStageDeconv, kStageInterp, kNumStages };
+struct StageTimer {
+    StageTimer(Stage stage, hipStream_t stream);
+    ~StageTimer();
+    int slot;
+    hipStream_t stream;
+};
+
 } // namespace nfft

@@ -12,6 +12,8 @@
 //     of being read back from HBM (reference: point_psi, 1.2 GB at N=256, n=1e7);
 //   * completed planes leave LDS as contiguous row segments of global_atomic_add_f32 (a row of a padded
 //     plane is one <=256-byte wave instruction), so HBM sees whole-line updates, never scattered dwords.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 #include "window.h"
@@ -21,7 +23,8 @@ namespace nfft {
 template <int DIM, int W>
 __global__ void __launch_bounds__((TapCfg<DIM, W>::NT))
 spread_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *__restrict__ spos,
-              const float *__restrict__ xs, const int64_t n, const int Cr, const int plane0, float *__restrict__ grid)
+              const float *__restrict__ xs, const int64_t n, const int Cr, const int plane0, float *__restrict__ grid,
+              const int dbg)
 {
     using C = TapCfg<DIM, W>;
     __shared__ float ring[C::LDS_FLOATS];
@@ -105,7 +108,8 @@ spread_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *_
 #pragma unroll
                                 for (int l0 = 0; l0 < C::W0; ++l0) {
                                     const int slot = (z0 + l0) & (C::R - 1);
-                                    atomicAdd(dst + slot * C::S0, w12 * readlane_f(psi0, l0));
+                                    if (dbg & 2) { if (dbg & 4) dst[slot * C::S0] = w12 * readlane_f(psi0, l0); else asm volatile("" ::"v"(w12 * readlane_f(psi0, l0)), "v"(dst + slot * C::S0)); }
+                                    else atomicAdd(dst + slot * C::S0, w12 * readlane_f(psi0, l0));
                                 }
                             } else {
                                 atomicAdd(dst, w12);
@@ -136,7 +140,8 @@ spread_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *_
                     const int64_t gz = DIM == 3 ? wrap(z, g.Ma[0]) : 0;
                     const int64_t g1 = DIM >= 2 ? wrap(tb1 - m + r, g.Ma[1]) : 0;
                     const int64_t g2 = wrap(tb2 - m + c, g.Ma[2]);
-                    atomicAdd(gplane + (gz * g.Ma[1] + g1) * g.Ma[2] + g2, v);
+                    if (dbg & 1) { if (dbg & 8) gplane[(gz * g.Ma[1] + g1) * g.Ma[2] + g2] = v; }
+                    else atomicAdd(gplane + (gz * g.Ma[1] + g1) * g.Ma[2] + g2, v);
                 }
             }
             __syncthreads();
@@ -152,7 +157,7 @@ static int launch_spread_t(const Geom &g, const int *tile_offsets, const float *
     using C = TapCfg<DIM, W>;
     const dim3 blocks((unsigned)(g.nta[1] * g.nta[2] * g.nseg), (unsigned)nplanes);
     hipLaunchKernelGGL((spread_kernel<DIM, W>), blocks, dim3(C::NT), 0, stream, g, tile_offsets, spos, xs, n, (int)Cr,
-                       (int)plane0, grid);
+                       (int)plane0, grid, getenv("NFFT_HIP_DBG") ? atoi(getenv("NFFT_HIP_DBG")) : 0);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }
