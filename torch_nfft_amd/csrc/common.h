@@ -28,12 +28,16 @@ void set_error(const std::string &msg);
 // segment of SEG chunks of one pencil.
 struct TileCfg {
     int T1, T2; // pencil cross-section (axis 1, axis 2)
-    int R;      // planes in the LDS ring (power of two)
-    int TC;     // planes per chunk along axis 0: R - (W - 1), so a chunk's taps fit the ring
+    int NP;     // planes resident in LDS while a chunk is processed
+    int TC;     // planes per chunk along axis 0: NP - (W - 1), so a chunk's taps fit the resident planes
 };
+// The spreading kernel accumulates in 8-byte cells (ds_add_f64: the 4-byte float LDS atomic is ~45x
+// slower on gfx950, see scripts/ubench/lds_ops.hip), which sets the LDS budget: NP * (T1+W-1) * (T2+W) * 8 B.
 constexpr TileCfg tile_cfg(int dim, int W)
 {
-    return dim == 3 ? (W <= 14 ? TileCfg{32, 32, 16, 16 - (W - 1)} : TileCfg{16, 16, 32, 32 - (W - 1)})
+    return dim == 3 ? (W <= 12 ? TileCfg{16, 32, 16, 16 - (W - 1)}
+                     : W <= 14 ? TileCfg{8, 32, 16, 16 - (W - 1)}
+                               : TileCfg{8, 16, 20, 20 - (W - 1)})
          : dim == 2 ? TileCfg{32, 32, 1, 1}
                     : TileCfg{1, 256, 1, 1};
 }

@@ -5,7 +5,9 @@
 //     y[i, c] = sum_{l in [0,2m+2)^d} prod_k psi_k(i, l_k) * g[(b, c), (shift_i + l) mod M],
 // as a true gather (the reference reduces the (2m+2)^d products of one output with atomics on y):
 //   * same tile-sorted point plan and pencil sweep as the spreading kernel;
-//   * the planes a chunk needs are staged once into an LDS ring with coalesced row loads;
+//   * the NP = TC + 2m+1 planes a chunk needs are resident in LDS: between chunks the 2m+1 still-needed
+//     planes slide down and only TC new ones are fetched (coalesced row loads), so every plane of a pencil
+//     is read from HBM/L2 once per segment;
 //   * one wave per point, lanes = (l1, l2) taps, axis-0 taps unrolled; the 64 partial sums are reduced
 //     with DPP row shifts/broadcasts (no LDS traffic) and the wave writes 64 outputs at a time.
 // g is held as real planes (re and im of a complex grid are separate planes = separate real columns).
@@ -33,14 +35,20 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
+template <int DIM>
+constexpr int interp_threads() { return DIM == 3 ? 512 : 256; }
+
 template <int DIM, int W>
-__global__ void __launch_bounds__((TapCfg<DIM, W>::NT))
+__global__ void __launch_bounds__((interp_threads<DIM>()))
 interp_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__restrict__ perm,
               const float *__restrict__ spos, const float *__restrict__ grid, const int Cr, const int plane0,
               float *__restrict__ yr)
 {
     using C = TapCfg<DIM, W>;
-    __shared__ float ring[C::LDS_FLOATS];
+    constexpr int NT = interp_threads<DIM>();
+    constexpr int NWAVES = NT / 64;
+    constexpr int PER_THREAD = (C::CELLS + NT - 1) / NT;
+    __shared__ float planes[C::CELLS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -72,62 +80,70 @@ interp_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__r
 
     const float *const gplane = grid + (int64_t)plane_local * g.cells;
 
-    int have_lo = 0, have_hi = 0;  // planes [have_lo, have_hi) (unwrapped) are resident in the ring
+    // Resident plane p holds the (unwrapped) grid plane base_z + p; planes [0, have) are valid.
+    int base_z = 0, have = 0;
 
     for (int k = k_begin; k < k_end; ++k) {
         const int s = tile_offsets[tile0 + k], e = tile_offsets[tile0 + k + 1];
         if (e == s) continue;
-        // planes touched by this chunk's points
-        const int need_lo = k * C::TC - C::M0OFF;
-        const int need_hi = min((k + 1) * C::TC, g.Ma[0]) + (C::W0 - 1 - C::M0OFF);
-        int load_lo = need_lo;
-        if (have_hi > need_lo && have_lo <= need_lo) load_lo = have_hi;  // overlap with what is resident
-        __syncthreads();  // every wave is done with the planes about to be replaced
-        {
-            const int total = (need_hi - load_lo) * C::S0;
-            for (int idx = tid; idx < total; idx += C::NT) {
-                const int pz = idx / C::S0;
-                const int rem = idx - pz * C::S0;
-                const int r = rem / C::S2;
-                const int c = rem - r * C::S2;
-                const int z = load_lo + pz;
-                float v = 0.0f;
-                if (c < C::P2) {
-                    const int64_t gz = DIM == 3 ? wrap(z, g.Ma[0]) : 0;
-                    const int64_t g1 = DIM >= 2 ? wrap(tb1 - m + r, g.Ma[1]) : 0;
-                    const int64_t g2 = wrap(tb2 - m + c, g.Ma[2]);
-                    v = gplane[(gz * g.Ma[1] + g1) * g.Ma[2] + g2];
+        const int want_z = k * C::TC - C::M0OFF;
+        // slide the planes that are still needed down, then fetch the missing ones (coalesced rows)
+        const int shift = have > 0 ? min(want_z - base_z, have) : 0;
+        const int kept = have - shift;
+        __syncthreads();  // every wave is done reading the planes about to move
+        float keep[PER_THREAD];
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int idx = tid + i * NT;
+            keep[i] = 0.0f;
+            if (idx < C::CELLS) {
+                const int p = idx / C::S0;
+                if (p < kept) {
+                    keep[i] = planes[idx + shift * C::S0];
+                } else {
+                    const int rem = idx - p * C::S0;
+                    const int r = rem / C::S2;
+                    const int c = rem - r * C::S2;
+                    if (c < C::P2) {
+                        const int64_t gz = DIM == 3 ? wrap(want_z + p, g.Ma[0]) : 0;
+                        const int64_t g1 = DIM >= 2 ? wrap(tb1 - m + r, g.Ma[1]) : 0;
+                        const int64_t g2 = wrap(tb2 - m + c, g.Ma[2]);
+                        keep[i] = gplane[(gz * g.Ma[1] + g1) * g.Ma[2] + g2];
+                    }
                 }
-                ring[((z + 4 * C::R) & (C::R - 1)) * C::S0 + rem] = v;
             }
         }
-        have_lo = need_lo;
-        have_hi = need_hi;
         __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int idx = tid + i * NT;
+            if (idx < C::CELLS) planes[idx] = keep[i];
+        }
+        base_z = want_z;
+        have = C::NP;
+        __syncthreads();
+        const int tb0 = k * C::TC;
 
-        const int len = (e - s + C::NWAVES - 1) / C::NWAVES;
+        const int len = (e - s + NWAVES - 1) / NWAVES;
         const int a = s + wave * len;
         const int bnd = min(e, a + len);
         for (int j0 = a; j0 < bnd; j0 += 64) {
             const int cnt = min(64, bnd - j0);
             PointPrep<DIM, W> pp;
-            if (lane < cnt) {
-                pp.load(g, spos, (int64_t)j0 + lane, tb1, tb2);
-            } else {
-                pp.f0 = pp.f1 = pp.f2 = 0.0f;
-                pp.base12 = 0;
-                pp.z0 = 0;
-            }
+            if (lane < cnt) pp.load(g, spos, (int64_t)j0 + lane, tb0, tb1, tb2);
+            else pp.clear();
             float result = 0.0f;
             for (int q = 0; q < cnt; ++q) {
                 const float f1 = readlane_f(pp.f1, q), f2 = readlane_f(pp.f2, q);
-                const int b12 = readlane_i(pp.base12, q);
-                float psi0 = 1.0f;
-                int z0 = 0;
+                const float *const origin = planes + readlane_i(pp.base, q);
+                float ps0[C::W0];
                 if (DIM == 3) {
                     const float d0 = readlane_f(pp.f0, q) + c0;
-                    psi0 = __builtin_amdgcn_exp2f(sc * d0 * d0);
-                    z0 = readlane_i(pp.z0, q) + 4 * C::R;
+                    const float psi0 = __builtin_amdgcn_exp2f(sc * d0 * d0);
+#pragma unroll
+                    for (int l0 = 0; l0 < C::W0; ++l0) ps0[l0] = readlane_f(psi0, l0);
+                } else {
+                    ps0[0] = 1.0f;
                 }
                 float acc = 0.0f;
 #pragma unroll
@@ -136,17 +152,10 @@ interp_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__r
                         const float d1 = f1 + taps.c1[p], d2 = f2 + taps.c2[p];
                         const float r2 = DIM >= 2 ? fmaf(d1, d1, d2 * d2) : d2 * d2;
                         const float w12 = __builtin_amdgcn_exp2f(sc * r2);
-                        const float *src = ring + b12 + taps.off[p];
+                        const float *src = origin + taps.off[p];
                         float part = 0.0f;
-                        if (DIM == 3) {
 #pragma unroll
-                            for (int l0 = 0; l0 < C::W0; ++l0) {
-                                const int slot = (z0 + l0) & (C::R - 1);
-                                part = fmaf(readlane_f(psi0, l0), src[slot * C::S0], part);
-                            }
-                        } else {
-                            part = *src;
-                        }
+                        for (int l0 = 0; l0 < C::W0; ++l0) part = fmaf(ps0[l0], src[l0 * C::S0], part);
                         acc = fmaf(w12, part, acc);
                     }
                 }
@@ -162,9 +171,8 @@ template <int DIM, int W>
 static int launch_interp_t(const Geom &g, const int *to, const int *perm, const float *spos, const float *grid,
                            int64_t Cr, int64_t plane0, int64_t nplanes, float *yr, hipStream_t stream)
 {
-    using C = TapCfg<DIM, W>;
     const dim3 blocks((unsigned)(g.nta[1] * g.nta[2] * g.nseg), (unsigned)nplanes);
-    hipLaunchKernelGGL((interp_kernel<DIM, W>), blocks, dim3(C::NT), 0, stream, g, to, perm, spos, grid, (int)Cr,
+    hipLaunchKernelGGL((interp_kernel<DIM, W>), blocks, dim3(interp_threads<DIM>()), 0, stream, g, to, perm, spos, grid, (int)Cr,
                        (int)plane0, yr);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;

@@ -5,13 +5,19 @@
 //     g[(b, c), (shift_i + l) mod M] += x[i, c] * prod_k psi_k(i, l_k),   l in [0, 2m+2)^d,
 // but organised for CDNA4:
 //   * points arrive counting-sorted by (pencil, chunk) tile (binning.hip);
-//   * one workgroup sweeps a segment of a T1 x T2 pencil along axis 0, accumulating into a ring of
-//     padded planes in LDS with ds_add_f32 -- one wave handles one point at a time, its lanes are the
-//     (l1, l2) taps, the l0 taps are an unrolled loop over ring planes;
-//   * the window is evaluated in registers (one v_exp_f32 per lane and pass plus one for axis 0) instead
-//     of being read back from HBM (reference: point_psi, 1.2 GB at N=256, n=1e7);
-//   * completed planes leave LDS as contiguous row segments of global_atomic_add_f32 (a row of a padded
-//     plane is one <=256-byte wave instruction), so HBM sees whole-line updates, never scattered dwords.
+//   * one workgroup sweeps a segment of a T1 x T2 pencil along axis 0.  NP = TC + 2m+1 padded planes are
+//     resident in LDS; a chunk of TC planes worth of points is accumulated, the finished planes are written
+//     out, the remaining 2m+1 planes slide down and the sweep continues -- the halo along axis 0 never
+//     leaves LDS;
+//   * one wave handles one point at a time: its lanes are the (l1, l2) taps of the point, the l0 taps are an
+//     unrolled loop with compile-time LDS offsets; the window is evaluated in registers (one v_exp_f32 per
+//     lane and pass plus one for axis 0) instead of being read back from HBM (reference: point_psi, 1.2 GB
+//     at N=256, n=1e7);
+//   * accumulation is ds_add_f64 on 8-byte cells.  Measured on MI355X (scripts/ubench/lds_ops.hip):
+//     ds_add_f32 193 cycles per wave instruction (serialised), ds_add_f64 8.2, ds_add_u32 4.3 -- the 32-bit
+//     float LDS atomic is unusable, the 64-bit one is native.  Side effect: tile sums are exact to fp64;
+//   * finished planes leave LDS as contiguous row segments of global_atomic_add_f32 (one padded row =
+//     one <=256-byte run of a wave instruction), so HBM sees line-sized updates, never scattered dwords.
 #include <cstdlib>
 
 #include "common.h"
@@ -20,14 +26,19 @@
 
 namespace nfft {
 
+template <int DIM>
+constexpr int spread_threads() { return DIM == 3 ? 1024 : 256; }
+
 template <int DIM, int W>
-__global__ void __launch_bounds__((TapCfg<DIM, W>::NT))
+__global__ void __launch_bounds__((spread_threads<DIM>()))
 spread_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *__restrict__ spos,
-              const float *__restrict__ xs, const int64_t n, const int Cr, const int plane0, float *__restrict__ grid,
-              const int dbg)
+              const float *__restrict__ xs, const int64_t n, const int Cr, const int plane0, float *__restrict__ grid)
 {
     using C = TapCfg<DIM, W>;
-    __shared__ float ring[C::LDS_FLOATS];
+    constexpr int NT = spread_threads<DIM>();
+    constexpr int NWAVES = NT / 64;
+    constexpr int PER_THREAD = (C::CELLS + NT - 1) / NT;
+    __shared__ double acc[C::CELLS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -48,7 +59,7 @@ spread_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *_
     const int tile0 = b * g.tiles_per_batch + pencil * g.nta[0];
     if (tile_offsets[tile0 + k_begin] == tile_offsets[tile0 + k_end]) return;  // no points in this segment
 
-    for (int i = tid; i < C::LDS_FLOATS; i += C::NT) ring[i] = 0.0f;
+    for (int i = tid; i < C::CELLS; i += NT) acc[i] = 0.0;
 
     const int m = g.m;
     const int tb1 = j1 * g.Ta[1], tb2 = j2 * g.Ta[2];
@@ -63,101 +74,106 @@ spread_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *_
     float *const gplane = grid + (int64_t)plane_local * g.cells;
     const float *const xcol = xs + (int64_t)cr * n;
 
-    int flushed = k_begin * C::TC - C::M0OFF;  // first plane (unwrapped) not yet written out
-    int dirty = flushed;                      // planes below this may hold data
-    __syncthreads();
+    // Resident plane p holds the (unwrapped) grid plane base_z + p.
+    int base_z = 0;
+    bool live = false;
 
+    // Write out the lowest `shift` planes, slide the others down, clear the top.
+    auto retire = [&](int shift) {
+        __syncthreads();
+        double keep[PER_THREAD];
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int idx = tid + i * NT;
+            keep[i] = 0.0;
+            if (idx < C::CELLS) {
+                const int p = idx / C::S0;
+                if (p < shift) {
+                    const double v = acc[idx];
+                    if (v != 0.0) {
+                        const int rem = idx - p * C::S0;
+                        const int r = rem / C::S2;
+                        const int c = rem - r * C::S2;
+                        const int64_t gz = DIM == 3 ? wrap(base_z + p, g.Ma[0]) : 0;
+                        const int64_t g1 = DIM >= 2 ? wrap(tb1 - m + r, g.Ma[1]) : 0;
+                        const int64_t g2 = wrap(tb2 - m + c, g.Ma[2]);
+                        atomicAdd(gplane + (gz * g.Ma[1] + g1) * g.Ma[2] + g2, (float)v);
+                    }
+                }
+                const int src = idx + shift * C::S0;
+                if (src < C::CELLS) keep[i] = acc[src];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int idx = tid + i * NT;
+            if (idx < C::CELLS) acc[idx] = keep[i];
+        }
+        __syncthreads();
+    };
+
+    __syncthreads();
     for (int k = k_begin; k < k_end; ++k) {
         const int s = tile_offsets[tile0 + k], e = tile_offsets[tile0 + k + 1];
-        if (e > s) {
-            // static split of the chunk's points over the waves
-            const int len = (e - s + C::NWAVES - 1) / C::NWAVES;
-            const int a = s + wave * len;
-            const int bnd = min(e, a + len);
-            for (int j0 = a; j0 < bnd; j0 += 64) {
-                const int cnt = min(64, bnd - j0);
-                PointPrep<DIM, W> pp;
-                float xv = 0.0f;
-                if (lane < cnt) {
-                    pp.load(g, spos, (int64_t)j0 + lane, tb1, tb2);
-                    xv = xcol[(int64_t)j0 + lane] * norm;
+        if (e == s) continue;
+        const int want_z = k * C::TC - C::M0OFF;
+        if (live && want_z != base_z) retire(min(want_z - base_z, C::NP));
+        base_z = want_z;
+        live = true;
+        const int tb0 = k * C::TC;
+
+        // static split of the chunk's points over the waves
+        const int len = (e - s + NWAVES - 1) / NWAVES;
+        const int a = s + wave * len;
+        const int bnd = min(e, a + len);
+        for (int j0 = a; j0 < bnd; j0 += 64) {
+            const int cnt = min(64, bnd - j0);
+            PointPrep<DIM, W> pp;
+            float xv = 0.0f;
+            if (lane < cnt) {
+                pp.load(g, spos, (int64_t)j0 + lane, tb0, tb1, tb2);
+                xv = xcol[(int64_t)j0 + lane] * norm;
+            } else {
+                pp.clear();
+            }
+            for (int q = 0; q < cnt; ++q) {
+                const float f1 = readlane_f(pp.f1, q), f2 = readlane_f(pp.f2, q);
+                const float xq = readlane_f(xv, q);
+                double *const origin = acc + readlane_i(pp.base, q);
+                float ps0[C::W0];
+                if (DIM == 3) {
+                    const float d0 = readlane_f(pp.f0, q) + c0;
+                    const float psi0 = __builtin_amdgcn_exp2f(sc * d0 * d0);
+#pragma unroll
+                    for (int l0 = 0; l0 < C::W0; ++l0) ps0[l0] = readlane_f(psi0, l0);
                 } else {
-                    pp.f0 = pp.f1 = pp.f2 = 0.0f;
-                    pp.base12 = 0;
-                    pp.z0 = 0;
+                    ps0[0] = 1.0f;
                 }
-                for (int q = 0; q < cnt; ++q) {
-                    const float f1 = readlane_f(pp.f1, q), f2 = readlane_f(pp.f2, q);
-                    const float xq = readlane_f(xv, q);
-                    const int b12 = readlane_i(pp.base12, q);
-                    float psi0 = 1.0f;
-                    int z0 = 0;
-                    if (DIM == 3) {
-                        const float d0 = readlane_f(pp.f0, q) + c0;
-                        psi0 = __builtin_amdgcn_exp2f(sc * d0 * d0);
-                        z0 = readlane_i(pp.z0, q) + 4 * C::R;  // keep the ring index non-negative
-                    }
 #pragma unroll
-                    for (int p = 0; p < C::PASSES; ++p) {
-                        if (taps.valid[p]) {
-                            const float d1 = f1 + taps.c1[p], d2 = f2 + taps.c2[p];
-                            const float r2 = DIM >= 2 ? fmaf(d1, d1, d2 * d2) : d2 * d2;
-                            const float w12 = __builtin_amdgcn_exp2f(sc * r2) * xq;
-                            float *dst = ring + b12 + taps.off[p];
-                            if (DIM == 3) {
+                for (int p = 0; p < C::PASSES; ++p) {
+                    if (taps.valid[p]) {
+                        const float d1 = f1 + taps.c1[p], d2 = f2 + taps.c2[p];
+                        const float r2 = DIM >= 2 ? fmaf(d1, d1, d2 * d2) : d2 * d2;
+                        const float w12 = __builtin_amdgcn_exp2f(sc * r2) * xq;
+                        double *dst = origin + taps.off[p];
 #pragma unroll
-                                for (int l0 = 0; l0 < C::W0; ++l0) {
-                                    const int slot = (z0 + l0) & (C::R - 1);
-                                    if (dbg & 2) { if (dbg & 4) dst[slot * C::S0] = w12 * readlane_f(psi0, l0); else asm volatile("" ::"v"(w12 * readlane_f(psi0, l0)), "v"(dst + slot * C::S0)); }
-                                    else atomicAdd(dst + slot * C::S0, w12 * readlane_f(psi0, l0));
-                                }
-                            } else {
-                                atomicAdd(dst, w12);
-                            }
-                        }
+                        for (int l0 = 0; l0 < C::W0; ++l0) atomicAdd(dst + l0 * C::S0, (double)(w12 * ps0[l0]));
                     }
                 }
             }
-            dirty = (k + 1) * C::TC + (C::W0 - 1 - C::M0OFF);
         }
-        // planes below `upto` receive no further taps from this segment
-        int upto = (k + 1) * C::TC - C::M0OFF;
-        if (k == k_end - 1) upto = min((k + 1) * C::TC, g.Ma[0]) + (C::W0 - 1 - C::M0OFF);
-        if (dirty > flushed) {
-            __syncthreads();
-            const int hi = min(upto, dirty);
-            const int total = (hi - flushed) * C::S0;
-            for (int idx = tid; idx < total; idx += C::NT) {
-                const int pz = idx / C::S0;
-                const int rem = idx - pz * C::S0;
-                const int r = rem / C::S2;
-                const int c = rem - r * C::S2;
-                const int z = flushed + pz;
-                float *src = ring + ((z + 4 * C::R) & (C::R - 1)) * C::S0 + rem;
-                const float v = *src;
-                if (v != 0.0f) {
-                    *src = 0.0f;
-                    const int64_t gz = DIM == 3 ? wrap(z, g.Ma[0]) : 0;
-                    const int64_t g1 = DIM >= 2 ? wrap(tb1 - m + r, g.Ma[1]) : 0;
-                    const int64_t g2 = wrap(tb2 - m + c, g.Ma[2]);
-                    if (dbg & 1) { if (dbg & 8) gplane[(gz * g.Ma[1] + g1) * g.Ma[2] + g2] = v; }
-                    else atomicAdd(gplane + (gz * g.Ma[1] + g1) * g.Ma[2] + g2, v);
-                }
-            }
-            __syncthreads();
-        }
-        flushed = upto;
     }
+    if (live) retire(C::NP);
 }
 
 template <int DIM, int W>
 static int launch_spread_t(const Geom &g, const int *tile_offsets, const float *spos, const float *xs, int64_t n,
                            int64_t Cr, int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream)
 {
-    using C = TapCfg<DIM, W>;
     const dim3 blocks((unsigned)(g.nta[1] * g.nta[2] * g.nseg), (unsigned)nplanes);
-    hipLaunchKernelGGL((spread_kernel<DIM, W>), blocks, dim3(C::NT), 0, stream, g, tile_offsets, spos, xs, n, (int)Cr,
-                       (int)plane0, grid, getenv("NFFT_HIP_DBG") ? atoi(getenv("NFFT_HIP_DBG")) : 0);
+    hipLaunchKernelGGL((spread_kernel<DIM, W>), blocks, dim3(spread_threads<DIM>()), 0, stream, g, tile_offsets, spos,
+                       xs, n, (int)Cr, (int)plane0, grid);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }

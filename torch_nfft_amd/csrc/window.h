@@ -8,7 +8,7 @@ namespace nfft {
 template <int DIM, int W>
 struct TapCfg {
     static constexpr TileCfg tc = tile_cfg(DIM, W);
-    static constexpr int T1 = tc.T1, T2 = tc.T2, R = tc.R, TC = tc.TC;
+    static constexpr int T1 = tc.T1, T2 = tc.T2, NP = tc.NP, TC = tc.TC;
     static constexpr int W0 = DIM == 3 ? W : 1;   // taps along axis 0
     static constexpr int W1 = DIM >= 2 ? W : 1;   // taps along axis 1
     static constexpr int M0OFF = DIM == 3 ? (W / 2 - 1) : 0;  // cutoff m on axis 0 (0 when degenerate)
@@ -18,14 +18,12 @@ struct TapCfg {
     // one point, enumerated row-major over the lanes, hit 32 consecutive LDS banks per half-wave.
     static constexpr int S2 = T2 + W;
     static constexpr int S0 = P1 * S2;            // plane stride (floats)
-    static constexpr int LDS_FLOATS = R * S0;
+    static constexpr int CELLS = NP * S0;         // resident cells
     static constexpr int TAPS12 = W1 * W;         // taps of one point inside a plane = lanes used
     static constexpr int PASSES = (TAPS12 + 63) / 64;
-    static constexpr int NT = DIM == 3 ? 512 : 256;
-    static constexpr int NWAVES = NT / 64;
-    static_assert((R & (R - 1)) == 0, "ring must be a power of two");
-    static_assert(DIM != 3 || TC >= 1, "chunk must hold at least one plane");
-    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+    static_assert(TC >= 1, "chunk must hold at least one plane");
+    static_assert(NP == TC + W0 - 1, "resident planes = chunk + halo");
+    static_assert(CELLS * 8 <= 160 * 1024, "LDS budget (8-byte cells)");
 };
 
 // Per-lane description of the in-plane taps (l1, l2) a lane evaluates in pass p: t = lane + 64 p.
@@ -61,9 +59,10 @@ template <int DIM, int W>
 struct PointPrep {
     using C = TapCfg<DIM, W>;
     float f0, f1, f2;  // fractional offsets per internal axis
-    int base12;        // (cell1 - tile_base1) * S2 + (cell2 - tile_base2): window origin inside the padded plane
-    int z0;            // cell0 - m: lowest plane touched (unwrapped)
-    __device__ __forceinline__ void load(const Geom &g, const float *__restrict__ spos, int64_t j, int tb1, int tb2)
+    int base;          // cell index of the window origin inside the resident planes:
+                       // ((cell0 - chunk_base0) * P1 + (cell1 - tile_base1)) * S2 + (cell2 - tile_base2)
+    __device__ __forceinline__ void load(const Geom &g, const float *__restrict__ spos, int64_t j, int tb0, int tb1,
+                                         int tb2)
     {
         int c0 = 0, c1 = 0, c2 = 0;
         f0 = f1 = f2 = 0.0f;
@@ -77,9 +76,9 @@ struct PointPrep {
         } else {
             split_cell(spos[j], g.M, c2, f2);
         }
-        base12 = (c1 - tb1) * C::S2 + (c2 - tb2);
-        z0 = c0 - C::M0OFF;
+        base = (c0 - tb0) * C::S0 + (c1 - tb1) * C::S2 + (c2 - tb2);
     }
+    __device__ __forceinline__ void clear() { f0 = f1 = f2 = 0.0f; base = 0; }
 };
 
 } // namespace nfft
