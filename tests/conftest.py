@@ -29,3 +29,18 @@ def rel_l2(a, b):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def ensure_built():
+    """Build libnfft_hip.so (hipcc cross-compiles without a GPU) and the C oracle if they are missing or stale."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_nfft_hip_build", os.path.join(ROOT, "torch_nfft_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build(verbose=False)
+    from oracle import ndft_cpu
+    ndft_cpu.build()
+
+
+def pytest_sessionstart(session):
+    ensure_built()
