@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnfft_hip.so")
+LIB_PATH = os.environ.get("NFFT_HIP_LIB") or os.path.join(_HERE, "libnfft_hip.so")
 
 ABI_VERSION = 1
 

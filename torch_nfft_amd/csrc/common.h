@@ -131,6 +131,15 @@ __device__ __forceinline__ int wrap(int v, int M)
     return v < 0 ? v + M : v;
 }
 
+// wrap for values known to lie within one period of [0, M) on either side (falls back to % otherwise)
+__device__ __forceinline__ int wrap_near(int v, int M)
+{
+    if (v < 0) v += M;
+    else if (v >= M) v -= M;
+    if (v < 0 || v >= M) v = wrap(v, M);
+    return v;
+}
+
 // Tile index of a point inside its batch: ((j1 * nt2 + j2) * nt0 + k0); chunks of one pencil are contiguous.
 __device__ __forceinline__ int tile_of_cells(const Geom &g, const int cell[3])
 {

@@ -47,7 +47,6 @@ interp_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__r
     using C = TapCfg<DIM, W>;
     constexpr int NT = interp_threads<DIM>();
     constexpr int NWAVES = NT / 64;
-    constexpr int PER_THREAD = (C::CELLS + NT - 1) / NT;
     __shared__ float planes[C::CELLS];
 
     const int tid = threadIdx.x;
@@ -87,37 +86,27 @@ interp_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__r
         const int s = tile_offsets[tile0 + k], e = tile_offsets[tile0 + k + 1];
         if (e == s) continue;
         const int want_z = k * C::TC - C::M0OFF;
-        // slide the planes that are still needed down, then fetch the missing ones (coalesced rows)
+        // slide the planes that are still needed down (linear LDS move in batches of `shift` planes: batch b
+        // only reads what batch b+1 overwrites), then fetch the missing planes row by row (one wave per padded
+        // row, lanes = columns: coalesced)
         const int shift = have > 0 ? min(want_z - base_z, have) : 0;
         const int kept = have - shift;
         __syncthreads();  // every wave is done reading the planes about to move
-        float keep[PER_THREAD];
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int idx = tid + i * NT;
-            keep[i] = 0.0f;
-            if (idx < C::CELLS) {
-                const int p = idx / C::S0;
-                if (p < kept) {
-                    keep[i] = planes[idx + shift * C::S0];
-                } else {
-                    const int rem = idx - p * C::S0;
-                    const int r = rem / C::S2;
-                    const int c = rem - r * C::S2;
-                    if (c < C::P2) {
-                        const int64_t gz = DIM == 3 ? wrap(want_z + p, g.Ma[0]) : 0;
-                        const int64_t g1 = DIM >= 2 ? wrap(tb1 - m + r, g.Ma[1]) : 0;
-                        const int64_t g2 = wrap(tb2 - m + c, g.Ma[2]);
-                        keep[i] = gplane[(gz * g.Ma[1] + g1) * g.Ma[2] + g2];
-                    }
-                }
+        if (kept > 0) {
+            for (int lo = 0; lo < kept * C::S0; lo += shift * C::S0) {
+                const int hi = min(lo + shift * C::S0, kept * C::S0);
+                for (int idx = lo + tid; idx < hi; idx += NT) planes[idx] = planes[idx + shift * C::S0];
+                __syncthreads();
             }
         }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int idx = tid + i * NT;
-            if (idx < C::CELLS) planes[idx] = keep[i];
+        for (int row = kept * C::P1 + wave; row < C::NP * C::P1; row += NWAVES) {
+            const int p = row / C::P1;
+            const int r = row - p * C::P1;
+            const int64_t gz = DIM == 3 ? wrap(want_z + p, g.Ma[0]) : 0;
+            const int64_t g1 = DIM >= 2 ? wrap(tb1 - m + r, g.Ma[1]) : 0;
+            const float *const grow = gplane + (gz * g.Ma[1] + g1) * g.Ma[2];
+            for (int c = lane; c < C::S2; c += 64)
+                planes[row * C::S2 + c] = c < C::P2 ? grow[wrap_near(tb2 - m + c, g.Ma[2])] : 0.0f;
         }
         base_z = want_z;
         have = C::NP;

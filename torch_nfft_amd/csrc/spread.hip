@@ -18,7 +18,6 @@
 //     float LDS atomic is unusable, the 64-bit one is native.  Side effect: tile sums are exact to fp64;
 //   * finished planes leave LDS as contiguous row segments of global_atomic_add_f32 (one padded row =
 //     one <=256-byte run of a wave instruction), so HBM sees line-sized updates, never scattered dwords.
-#include <cstdlib>
 
 #include "common.h"
 #include "kernels.h"
@@ -37,7 +36,6 @@ spread_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *_
     using C = TapCfg<DIM, W>;
     constexpr int NT = spread_threads<DIM>();
     constexpr int NWAVES = NT / 64;
-    constexpr int PER_THREAD = (C::CELLS + NT - 1) / NT;
     __shared__ double acc[C::CELLS];
 
     const int tid = threadIdx.x;
@@ -79,36 +77,33 @@ spread_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *_
     bool live = false;
 
     // Write out the lowest `shift` planes, slide the others down, clear the top.
+    // Batch 0 visits the retiring planes row by row (one wave per padded row, lanes = columns, so a row
+    // leaves as one contiguous run of global atomics) and refills them from `shift` planes above; the
+    // remaining batches are a linear LDS move.  Batch b only reads what batch b+1 will overwrite.
     auto retire = [&](int shift) {
         __syncthreads();
-        double keep[PER_THREAD];
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int idx = tid + i * NT;
-            keep[i] = 0.0;
-            if (idx < C::CELLS) {
-                const int p = idx / C::S0;
-                if (p < shift) {
-                    const double v = acc[idx];
-                    if (v != 0.0) {
-                        const int rem = idx - p * C::S0;
-                        const int r = rem / C::S2;
-                        const int c = rem - r * C::S2;
-                        const int64_t gz = DIM == 3 ? wrap(base_z + p, g.Ma[0]) : 0;
-                        const int64_t g1 = DIM >= 2 ? wrap(tb1 - m + r, g.Ma[1]) : 0;
-                        const int64_t g2 = wrap(tb2 - m + c, g.Ma[2]);
-                        atomicAdd(gplane + (gz * g.Ma[1] + g1) * g.Ma[2] + g2, (float)v);
-                    }
-                }
+        const int rows = shift * C::P1;
+        for (int row = wave; row < rows; row += NWAVES) {
+            const int p = row / C::P1;
+            const int r = row - p * C::P1;
+            const int64_t gz = DIM == 3 ? wrap(base_z + p, g.Ma[0]) : 0;
+            const int64_t g1 = DIM >= 2 ? wrap(tb1 - m + r, g.Ma[1]) : 0;
+            float *const grow = gplane + (gz * g.Ma[1] + g1) * g.Ma[2];
+            for (int c = lane; c < C::S2; c += 64) {
+                const int idx = row * C::S2 + c;
+                const double v = acc[idx];
                 const int src = idx + shift * C::S0;
-                if (src < C::CELLS) keep[i] = acc[src];
+                acc[idx] = src < C::CELLS ? acc[src] : 0.0;
+                if (v != 0.0) atomicAdd(grow + wrap_near(tb2 - m + c, g.Ma[2]), (float)v);
             }
         }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int idx = tid + i * NT;
-            if (idx < C::CELLS) acc[idx] = keep[i];
+        for (int lo = shift * C::S0; lo < C::CELLS; lo += shift * C::S0) {
+            __syncthreads();
+            const int hi = min(lo + shift * C::S0, C::CELLS);
+            for (int idx = lo + tid; idx < hi; idx += NT) {
+                const int src = idx + shift * C::S0;
+                acc[idx] = src < C::CELLS ? acc[src] : 0.0;
+            }
         }
         __syncthreads();
     };
