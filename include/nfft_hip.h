@@ -80,6 +80,15 @@ int nfft_hip_forward(const nfft_hip_problem *p, const float *pos, const void *xh
                      const int64_t *batch, int real_output, void *y,
                      void *workspace, int64_t workspace_bytes, void *stream);
 
+/* The same two transforms on an existing point plan (nfft_hip_plan_points below): the plan depends only on
+ * (pos, batch, N, m) and can be shared by any number of adjoint / forward calls on the same points -- the
+ * reference re-derives shifts and psi in every call but reuses them when sources.is_same(targets)
+ * (core_cuda.cu:552-564).  The workspace sizes are those of the un-planned calls. */
+int nfft_hip_adjoint_planned(const nfft_hip_problem *p, const void *plan, const void *x, int x_is_complex,
+                             int real_output, void *y, void *workspace, int64_t workspace_bytes, void *stream);
+int nfft_hip_forward_planned(const nfft_hip_problem *p, const void *plan, const void *xhat, int x_is_complex,
+                             int real_output, void *y, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ---- stage-level entry points (used by the parity tests and by bench.py to time
  * the spreading kernel on its own; the two calls above are built from them) ---- */
 

@@ -19,6 +19,8 @@ SYMBOLS = (
     "nfft_hip_forward_workspace_bytes",
     "nfft_hip_adjoint",
     "nfft_hip_forward",
+    "nfft_hip_adjoint_planned",
+    "nfft_hip_forward_planned",
     "nfft_hip_plan_bytes",
     "nfft_hip_plan_points",
     "nfft_hip_spread",
@@ -67,6 +69,9 @@ def load():
         f.restype = i64
     for f in (lib.nfft_hip_adjoint, lib.nfft_hip_forward):
         f.argtypes = [P, vp, vp, ci, vp, ci, vp, vp, i64, vp]
+        f.restype = ci
+    for f in (lib.nfft_hip_adjoint_planned, lib.nfft_hip_forward_planned):
+        f.argtypes = [P, vp, vp, ci, ci, vp, vp, i64, vp]
         f.restype = ci
     lib.nfft_hip_plan_bytes.argtypes = [P]
     lib.nfft_hip_plan_bytes.restype = i64

@@ -192,6 +192,7 @@ int nfft_hip_plan_points(const nfft_hip_problem *p, const float *pos, const int6
     const PlanLayout L = plan_layout(g, p->num_points, p->batch_size);
     if (!plan || plan_bytes < L.total) { set_error("plan buffer too small"); return NFFT_HIP_EWORKSPACE; }
     if (p->num_points > 0 && !pos) { set_error("Input mismatch: pos is null"); return NFFT_HIP_EINVAL; }
+    StageTimer t(kStagePlan, (hipStream_t)stream);
     return launch_plan_points(g, L, pos, batch, p->num_points, p->batch_size, plan, (hipStream_t)stream);
 }
 
@@ -220,9 +221,9 @@ int nfft_hip_interpolate(const nfft_hip_problem *p, const void *plan, const floa
     return launch_interp(g, L, plan, grid, p->num_points, real_columns, 0, planes, yr, (hipStream_t)stream);
 }
 
-int nfft_hip_adjoint(const nfft_hip_problem *p, const float *pos, const void *x, int x_is_complex,
-                     const int64_t *batch, int real_output, void *y, void *workspace, int64_t workspace_bytes,
-                     void *stream)
+static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64_t *batch, const void *ext_plan,
+                        const void *x, int x_is_complex, int real_output, void *y, void *workspace,
+                        int64_t workspace_bytes, void *stream)
 {
     if (int rc = validate(p)) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -231,16 +232,20 @@ int nfft_hip_adjoint(const nfft_hip_problem *p, const float *pos, const void *x,
     if (int rc = make_carve(p, ppc, true, kR2C, c)) return rc;
     if (c.total_planes == 0) return 0;
     if (!y) { set_error("Input mismatch: y is null"); return NFFT_HIP_EINVAL; }
-    if (c.n > 0 && (!pos || !x)) { set_error("Input mismatch: null input"); return NFFT_HIP_EINVAL; }
+    if (c.n > 0 && ((!pos && !ext_plan) || !x)) { set_error("Input mismatch: null input"); return NFFT_HIP_EINVAL; }
     if (!workspace || workspace_bytes < c.total) { set_error("workspace too small"); return NFFT_HIP_EWORKSPACE; }
     char *ws = (char *)(((uintptr_t)workspace + 255) & ~uintptr_t(255));
-    void *plan = ws + c.off_plan;
+    const void *plan = ext_plan;
     float *xs = (float *)(ws + c.off_xs);
     float *grid = (float *)(ws + c.off_grid);
     float2 *spec = (float2 *)(ws + c.off_spec);
     void *work = ws + c.off_work;
 
-    { StageTimer t(kStagePlan, s); if (int rc = launch_plan_points(c.g, c.L, pos, batch, c.n, c.B, plan, s)) return rc; }
+    if (!ext_plan) {
+        StageTimer t(kStagePlan, s);
+        if (int rc = launch_plan_points(c.g, c.L, pos, batch, c.n, c.B, ws + c.off_plan, s)) return rc;
+        plan = ws + c.off_plan;
+    }
     { StageTimer t(kStageGather, s); if (int rc = launch_gather_rows(c.g, c.L, plan, c.n, (const float *)x, c.Cr, xs, s)) return rc; }
     for (int64_t p0 = 0; p0 < c.total_planes; p0 += c.chunk_planes) {
         const int64_t np = std::min(c.chunk_planes, c.total_planes - p0);
@@ -252,9 +257,9 @@ int nfft_hip_adjoint(const nfft_hip_problem *p, const float *pos, const void *x,
     return 0;
 }
 
-int nfft_hip_forward(const nfft_hip_problem *p, const float *pos, const void *xhat, int x_is_complex,
-                     const int64_t *batch, int real_output, void *y, void *workspace, int64_t workspace_bytes,
-                     void *stream)
+static int forward_impl(const nfft_hip_problem *p, const float *pos, const int64_t *batch, const void *ext_plan,
+                        const void *xhat, int x_is_complex, int real_output, void *y, void *workspace,
+                        int64_t workspace_bytes, void *stream)
 {
     if (int rc = validate(p)) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -262,15 +267,19 @@ int nfft_hip_forward(const nfft_hip_problem *p, const float *pos, const void *xh
     Carve c;
     if (int rc = make_carve(p, ppc, false, kC2R, c)) return rc;
     if (c.total_planes == 0 || c.n == 0) return 0;
-    if (!y || !pos || !xhat) { set_error("Input mismatch: null input"); return NFFT_HIP_EINVAL; }
+    if (!y || (!pos && !ext_plan) || !xhat) { set_error("Input mismatch: null input"); return NFFT_HIP_EINVAL; }
     if (!workspace || workspace_bytes < c.total) { set_error("workspace too small"); return NFFT_HIP_EWORKSPACE; }
     char *ws = (char *)(((uintptr_t)workspace + 255) & ~uintptr_t(255));
-    void *plan = ws + c.off_plan;
+    const void *plan = ext_plan;
     float *grid = (float *)(ws + c.off_grid);
     float2 *spec = (float2 *)(ws + c.off_spec);
     void *work = ws + c.off_work;
 
-    { StageTimer t(kStagePlan, s); if (int rc = launch_plan_points(c.g, c.L, pos, batch, c.n, c.B, plan, s)) return rc; }
+    if (!ext_plan) {
+        StageTimer t(kStagePlan, s);
+        if (int rc = launch_plan_points(c.g, c.L, pos, batch, c.n, c.B, ws + c.off_plan, s)) return rc;
+        plan = ws + c.off_plan;
+    }
     for (int64_t p0 = 0; p0 < c.total_planes; p0 += c.chunk_planes) {
         const int64_t np = std::min(c.chunk_planes, c.total_planes - p0);
         { StageTimer t(kStageDeconv, s); if (int rc = launch_deconv_forward(c.g, xhat, c.C, x_is_complex, real_output, p0, np, spec, s)) return rc; }
@@ -278,6 +287,34 @@ int nfft_hip_forward(const nfft_hip_problem *p, const float *pos, const void *xh
         { StageTimer t(kStageInterp, s); if (int rc = launch_interp(c.g, c.L, plan, grid, c.n, c.Cr, p0, np, (float *)y, s)) return rc; }
     }
     return 0;
+}
+
+int nfft_hip_adjoint(const nfft_hip_problem *p, const float *pos, const void *x, int x_is_complex,
+                     const int64_t *batch, int real_output, void *y, void *workspace, int64_t workspace_bytes,
+                     void *stream)
+{
+    return adjoint_impl(p, pos, batch, nullptr, x, x_is_complex, real_output, y, workspace, workspace_bytes, stream);
+}
+
+int nfft_hip_forward(const nfft_hip_problem *p, const float *pos, const void *xhat, int x_is_complex,
+                     const int64_t *batch, int real_output, void *y, void *workspace, int64_t workspace_bytes,
+                     void *stream)
+{
+    return forward_impl(p, pos, batch, nullptr, xhat, x_is_complex, real_output, y, workspace, workspace_bytes, stream);
+}
+
+int nfft_hip_adjoint_planned(const nfft_hip_problem *p, const void *plan, const void *x, int x_is_complex,
+                             int real_output, void *y, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (!plan) { set_error("Input mismatch: plan is null"); return NFFT_HIP_EINVAL; }
+    return adjoint_impl(p, nullptr, nullptr, plan, x, x_is_complex, real_output, y, workspace, workspace_bytes, stream);
+}
+
+int nfft_hip_forward_planned(const nfft_hip_problem *p, const void *plan, const void *xhat, int x_is_complex,
+                             int real_output, void *y, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (!plan) { set_error("Input mismatch: plan is null"); return NFFT_HIP_EINVAL; }
+    return forward_impl(p, nullptr, nullptr, plan, xhat, x_is_complex, real_output, y, workspace, workspace_bytes, stream);
 }
 
 } // extern "C"

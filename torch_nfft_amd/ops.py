@@ -14,6 +14,55 @@ from . import _lib
 
 _ws_bytes_cache = {}
 
+# Point-plan reuse.  The tile-sorted copy of the points depends only on
+# (pos, batch, N, m); adjoint <-> forward pairs (autograd backward, a forward fed by an adjoint, fastsum with
+# shared points -- the reference exploits sources.is_same(targets), core_cuda.cu:552-564) reuse it instead of
+# re-binning.  The cache holds ONE plan, keyed on tensor identity + version counter, so in-place edits of pos
+# invalidate it.  `plan_cache_enabled(False)` turns it off; `plan_cache_clear()` drops the held plan.
+_plan_cache = {"key": None, "plan": None, "enabled": True, "hits": 0, "misses": 0}
+
+
+def plan_cache_enabled(flag):
+    _plan_cache["enabled"] = bool(flag)
+    if not flag:
+        plan_cache_clear()
+
+
+def plan_cache_clear():
+    _plan_cache["key"] = None
+    _plan_cache["plan"] = None
+
+
+def plan_cache_stats():
+    return {"hits": _plan_cache["hits"], "misses": _plan_cache["misses"]}
+
+
+def _get_plan(prob, pos, batch, stream):
+    """Returns (plan_tensor, fresh) -- the cached plan for these points or a newly built one."""
+    lib = _lib.load()
+    key = (pos.data_ptr(), pos._version, tuple(pos.shape), pos.device.index,
+           None if batch is None else (batch.data_ptr(), batch._version), prob.batch_size, prob.N, prob.m)
+    if _plan_cache["enabled"] and _plan_cache["key"] == key:
+        _plan_cache["hits"] += 1
+        return _plan_cache["plan"]
+    nbytes = lib.nfft_hip_plan_bytes(ctypes.byref(prob))
+    if nbytes < 0:
+        _lib.check(_lib.EINVAL)
+    plan = torch.empty(int(nbytes), dtype=torch.uint8, device=pos.device)
+    _lib.check(lib.nfft_hip_plan_points(ctypes.byref(prob), _ptr(pos), _ptr(batch), _ptr(plan), plan.numel(),
+                                        ctypes.c_void_p(stream)))
+    _plan_cache["misses"] += 1
+    if _plan_cache["enabled"]:
+        # keep the tensors alive so that data_ptr identity cannot be recycled while the plan is cached
+        _plan_cache["key"] = key
+        _plan_cache["plan"] = plan
+        _plan_cache["refs"] = (pos, batch)
+    return plan
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
 
 def _assert_input(cond):
     if not cond:
@@ -65,10 +114,6 @@ def _workspace(kind, prob, x_is_complex, real_output, device):
     return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
 
 
-def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
-
-
 def nfft_adjoint(pos, x, batch, N, m, real_output):
     """torch_nfft::nfft_adjoint(Tensor pos, Tensor x, Tensor? batch, int N, int m, int real_output) -> Tensor
     (csrc/core.cpp:43-55; driver core_cuda.cu:144-336)."""
@@ -91,9 +136,10 @@ def nfft_adjoint(pos, x, batch, N, m, real_output):
     with torch.cuda.device(x.device):
         ws = _workspace("adjoint", prob, 0 if real_input else 1, real_output, x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        rc = _lib.load().nfft_hip_adjoint(ctypes.byref(prob), _ptr(pos_c), _ptr(x_c), 0 if real_input else 1,
-                                          _ptr(batch_c), real_output, _ptr(y), _ptr(ws), ws.numel(),
-                                          ctypes.c_void_p(stream))
+        plan = _get_plan(prob, pos_c, batch_c, stream)
+        rc = _lib.load().nfft_hip_adjoint_planned(ctypes.byref(prob), _ptr(plan), _ptr(x_c), 0 if real_input else 1,
+                                                  real_output, _ptr(y), _ptr(ws), ws.numel(),
+                                                  ctypes.c_void_p(stream))
     _lib.check(rc)
     return y
 
@@ -124,9 +170,10 @@ def nfft_forward(pos, x, batch, m, real_output):
     with torch.cuda.device(x.device):
         ws = _workspace("forward", prob, 0 if real_input else 1, real_output, x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        rc = _lib.load().nfft_hip_forward(ctypes.byref(prob), _ptr(pos_c), _ptr(x_c), 0 if real_input else 1,
-                                          _ptr(batch_c), real_output, _ptr(y), _ptr(ws), ws.numel(),
-                                          ctypes.c_void_p(stream))
+        plan = _get_plan(prob, pos_c, batch_c, stream)
+        rc = _lib.load().nfft_hip_forward_planned(ctypes.byref(prob), _ptr(plan), _ptr(x_c), 0 if real_input else 1,
+                                                  real_output, _ptr(y), _ptr(ws), ws.numel(),
+                                                  ctypes.c_void_p(stream))
     _lib.check(rc)
     return y
 
