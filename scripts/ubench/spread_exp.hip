@@ -164,10 +164,21 @@ spread_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *_
                     if (taps.valid[p]) {
                         const float d1 = f1 + taps.c1[p], d2 = f2 + taps.c2[p];
                         const float r2 = DIM >= 2 ? fmaf(d1, d1, d2 * d2) : d2 * d2;
-                        const float w12 = __builtin_amdgcn_exp2f(sc * r2) * xq;
+                        const float w12 = __builtin_amdgcn_exp2f(sc * r2) * xq * (EXP == 4 || EXP == 5 ? 1e7f : 1.0f);
                         double *dst = origin + taps.off[p];
 #pragma unroll
-                        for (int l0 = 0; l0 < C::W0; ++l0) atomicAdd(dst + l0 * C::S0, (double)(w12 * ps0[l0]));
+                        for (int l0 = 0; l0 < C::W0; ++l0) {
+#if EXP == 4
+                            const int q = (int)(w12 * ps0[l0]);
+                            const unsigned long long v64 = (unsigned long long)(long long)q;
+                            atomicAdd((unsigned long long *)(dst + l0 * C::S0), v64);
+#elif EXP == 5
+                            const int q = (int)(w12 * ps0[l0]);
+                            atomicAdd((unsigned int *)(dst + l0 * C::S0), (unsigned)q);
+#else
+                            atomicAdd(dst + l0 * C::S0, (double)(w12 * ps0[l0]));
+#endif
+                        }
                     }
                 }
             }

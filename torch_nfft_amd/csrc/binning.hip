@@ -11,19 +11,30 @@
 
 namespace nfft {
 
+constexpr int kSortBlockPoints = 4096;  // points per workgroup in the first-level passes
+constexpr int kSortThreads = 256;
+constexpr int kMaxPencilsLds = 8192;    // first-level bins that fit an LDS histogram
+
 PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)
 {
     PlanLayout L;
     L.ntiles = (int64_t)g.tiles_per_batch * B;
-    size_t scan_bytes = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int *)nullptr, (int *)nullptr, (int)(L.ntiles + 1));
-    L.scan_bytes = (int64_t)scan_bytes;
+    L.npencils = (int64_t)g.nta[1] * g.nta[2] * B;
+    L.nblocks = (n + kSortBlockPoints - 1) / kSortBlockPoints;
+    L.two_level = L.npencils <= kMaxPencilsLds && L.npencils * L.nblocks < (int64_t(1) << 28) && n > 0;
+    const int64_t scan_items = L.two_level ? L.npencils * L.nblocks + 1 : L.ntiles + 1;
+    // hipcub's temporary storage for an int scan grows with the item count; bound it without touching the device
+    L.scan_bytes = align_up(scan_items / 64 + 65536, 256);
     int64_t o = 0;
     L.off_offsets = o; o = align_up(o + (L.ntiles + 1) * 4, 256);
     L.off_cursor = o;  o = align_up(o + (L.ntiles + 1) * 4, 256);
     L.off_perm = o;    o = align_up(o + n * 4, 256);
     L.off_spos = o;    o = align_up(o + n * g.dim * 4, 256);
     L.off_scan = o;    o = align_up(o + L.scan_bytes, 256);
+    // scratch of the two-level sort: per-(pencil, block) counts + their scan, and the pencil-ordered records
+    L.off_hist = o;    o = align_up(o + (L.two_level ? scan_items * 4 : 0), 256);
+    L.off_hscan = o;   o = align_up(o + (L.two_level ? scan_items * 4 : 0), 256);
+    L.off_tmp = o;     o = align_up(o + (L.two_level ? n * 16 : 0), 256);
     L.total = o;
     return L;
 }
@@ -62,6 +73,124 @@ __global__ void __launch_bounds__(256) bin_fill_kernel(Geom g, const float *__re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-level counting sort without global atomics.
+//   level 1: (batch, pencil) bins.  Each workgroup owns a slice of kSortBlockPoints points, histograms it in
+//            LDS (ds_add_u32 runs at the ds_write_b32 rate), the per-(pencil, block) counts are scanned on
+//            the device, and the slice is scattered with LDS cursors -> records grouped by pencil.
+//   level 2: one workgroup per pencil counting-sorts its records by chunk in LDS and writes the final
+//            tile offsets, the tile-ordered positions and the permutation.
+__device__ __forceinline__ void point_cells(const Geom &g, const float *__restrict__ pos, int64_t i, int cell[3])
+{
+    cell[0] = cell[1] = cell[2] = 0;
+    for (int u = 0; u < g.dim; ++u) {
+        float fr;
+        split_cell(pos[i * g.dim + u], g.M, cell[u + 3 - g.dim], fr);
+    }
+}
+
+__device__ __forceinline__ int pencil_of(const Geom &g, const int cell[3], int64_t b)
+{
+    return ((int)b * g.nta[1] + cell[1] / g.Ta[1]) * g.nta[2] + cell[2] / g.Ta[2];
+}
+
+__global__ void __launch_bounds__(kSortThreads)
+sort1_count_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restrict__ batch, int64_t n, int64_t B,
+                   int npencils, int nblocks, int *__restrict__ hist /* [pencil][block] */)
+{
+    extern __shared__ int lds_hist[];
+    for (int i = threadIdx.x; i < npencils; i += kSortThreads) lds_hist[i] = 0;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * kSortBlockPoints;
+    const int64_t hi = min(n, lo + kSortBlockPoints);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kSortThreads) {
+        int cell[3];
+        point_cells(g, pos, i, cell);
+        int64_t b = batch ? batch[i] : 0;
+        b = b < 0 ? 0 : (b >= B ? B - 1 : b);
+        atomicAdd(&lds_hist[pencil_of(g, cell, b)], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < npencils; i += kSortThreads) hist[(int64_t)i * nblocks + blockIdx.x] = lds_hist[i];
+}
+
+__global__ void __launch_bounds__(kSortThreads)
+sort1_scatter_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restrict__ batch, int64_t n, int64_t B,
+                     int npencils, int nblocks, const int *__restrict__ hscan, float4 *__restrict__ tmp)
+{
+    extern __shared__ int lds_cur[];
+    for (int i = threadIdx.x; i < npencils; i += kSortThreads) lds_cur[i] = hscan[(int64_t)i * nblocks + blockIdx.x];
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * kSortBlockPoints;
+    const int64_t hi = min(n, lo + kSortBlockPoints);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kSortThreads) {
+        int cell[3];
+        point_cells(g, pos, i, cell);
+        int64_t b = batch ? batch[i] : 0;
+        b = b < 0 ? 0 : (b >= B ? B - 1 : b);
+        const int slot = atomicAdd(&lds_cur[pencil_of(g, cell, b)], 1);
+        float4 rec;
+        rec.x = pos[i * g.dim];
+        rec.y = g.dim > 1 ? pos[i * g.dim + 1] : 0.f;
+        rec.z = g.dim > 2 ? pos[i * g.dim + 2] : 0.f;
+        rec.w = __int_as_float((int)i);
+        tmp[slot] = rec;
+    }
+}
+
+__global__ void __launch_bounds__(kSortThreads)
+sort2_kernel(Geom g, int64_t n, int npencils, int nblocks, const int *__restrict__ hscan,
+             const float4 *__restrict__ tmp, int *__restrict__ offsets, int *__restrict__ perm,
+             float *__restrict__ spos)
+{
+    extern __shared__ int lds2[];  // [nt0] counts -> cursors, + scan scratch
+    const int pencil = blockIdx.x;
+    const int nt0 = g.nta[0];
+    const int p0 = hscan[(int64_t)pencil * nblocks];
+    const int p1 = pencil + 1 < npencils ? hscan[(int64_t)(pencil + 1) * nblocks] : (int)n;
+    for (int i = threadIdx.x; i < nt0; i += kSortThreads) lds2[i] = 0;
+    __syncthreads();
+    for (int j = p0 + threadIdx.x; j < p1; j += kSortThreads) {
+        int c0 = 0;
+        float fr;
+        if (g.dim == 3) split_cell(tmp[j].x, g.M, c0, fr);
+        atomicAdd(&lds2[c0 / g.Ta[0]], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the nt0 chunk counts by one wave (nt0 is small: M / TC)
+    if (threadIdx.x < 64) {
+        int carry = 0;
+        for (int base = 0; base < nt0; base += 64) {
+            const int idx = base + threadIdx.x;
+            const int v = idx < nt0 ? lds2[idx] : 0;
+            int incl = v;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off);
+                if ((int)threadIdx.x >= off) incl += t;
+            }
+            if (idx < nt0) {
+                const int excl = carry + incl - v;
+                lds2[idx] = excl;                      // cursor of chunk idx (relative to p0)
+                offsets[(int64_t)pencil * nt0 + idx] = p0 + excl;
+            }
+            carry += __shfl(incl, 63);
+        }
+        if (pencil == npencils - 1 && threadIdx.x == 0) offsets[(int64_t)npencils * nt0] = (int)n;
+    }
+    __syncthreads();
+    for (int j = p0 + threadIdx.x; j < p1; j += kSortThreads) {
+        const float4 rec = tmp[j];
+        int c0 = 0;
+        float fr;
+        if (g.dim == 3) split_cell(rec.x, g.M, c0, fr);
+        const int slot = p0 + atomicAdd(&lds2[c0 / g.Ta[0]], 1);
+        perm[slot] = __float_as_int(rec.w);
+        spos[(int64_t)slot * g.dim] = rec.x;
+        if (g.dim > 1) spos[(int64_t)slot * g.dim + 1] = rec.y;
+        if (g.dim > 2) spos[(int64_t)slot * g.dim + 2] = rec.z;
+    }
+}
+
 // xs[c, slot] = xr[perm[slot], c]  (tile-ordered, column-major copy of the real coefficient columns)
 __global__ void __launch_bounds__(256) gather_rows_kernel(const int *__restrict__ perm, const float *__restrict__ xr,
                                                          float *__restrict__ xs, int64_t n, int64_t cols)
@@ -89,12 +218,34 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
     int *cursor = (int *)(base + L.off_cursor);
     int *perm = (int *)(base + L.off_perm);
     float *spos = (float *)(base + L.off_spos);
+    if (L.two_level) {
+        int *hist = (int *)(base + L.off_hist);
+        int *hscan = (int *)(base + L.off_hscan);
+        float4 *tmp = (float4 *)(base + L.off_tmp);
+        const int npencils = (int)L.npencils, nblocks = (int)L.nblocks;
+        const int64_t items = L.npencils * L.nblocks + 1;
+        const size_t lds1 = (size_t)npencils * 4;
+        hipLaunchKernelGGL(sort1_count_kernel, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
+                           npencils, nblocks, hist);
+        size_t scan_bytes = 0;
+        NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, hist, hscan, (int)items, stream));
+        if ((int64_t)scan_bytes > L.scan_bytes) { set_error("scan scratch too small"); return 2; }
+        NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(base + L.off_scan, scan_bytes, hist, hscan, (int)items, stream));
+        hipLaunchKernelGGL(sort1_scatter_kernel, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
+                           npencils, nblocks, hscan, tmp);
+        hipLaunchKernelGGL(sort2_kernel, dim3(npencils), dim3(kSortThreads), (size_t)g.nta[0] * 4, stream, g, n,
+                           npencils, nblocks, hscan, tmp, offsets, perm, spos);
+        NFFT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     // counts are accumulated in `cursor`, scanned into `offsets`, then `cursor` restarts at zero
     NFFT_HIP_CHECK(hipMemsetAsync(cursor, 0, (L.ntiles + 1) * 4, stream));
     if (n > 0) {
         hipLaunchKernelGGL(bin_count_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, g, pos, batch, n, B, cursor);
     }
-    size_t scan_bytes = (size_t)L.scan_bytes;
+    size_t scan_bytes = 0;
+    NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, cursor, offsets, (int)(L.ntiles + 1), stream));
+    if ((int64_t)scan_bytes > L.scan_bytes) { set_error("scan scratch too small"); return 2; }
     NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(base + L.off_scan, scan_bytes, cursor, offsets,
                                                     (int)(L.ntiles + 1), stream));
     NFFT_HIP_CHECK(hipMemsetAsync(cursor, 0, (L.ntiles + 1) * 4, stream));

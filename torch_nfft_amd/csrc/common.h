@@ -152,10 +152,13 @@ __device__ __forceinline__ int tile_of_cells(const Geom &g, const int cell[3])
 #endif // __HIPCC__
 
 // ---- plan layout -----------------------------------------------------------
-// [ tile_offset int32[ntiles+1] | cursor int32[ntiles] | perm int32[n] | spos float[n*dim] | scan temp ]
+// [ tile_offset int32[ntiles+1] | cursor int32[ntiles] | perm int32[n] | spos float[n*dim] | scan temp | sort scratch ]
 struct PlanLayout {
     int64_t ntiles;
+    int64_t npencils, nblocks;  // two-level sort geometry
+    bool two_level;
     int64_t off_offsets, off_cursor, off_perm, off_spos, off_scan, scan_bytes;
+    int64_t off_hist, off_hscan, off_tmp;
     int64_t total;
 };
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
