@@ -320,6 +320,45 @@ def test_chunked_planes_path(tn, monkeypatch):
     ops._ws_bytes_cache.clear()
 
 
+def test_full_rocfft_path_when_column_passes_disabled(tn, monkeypatch):
+    """3-D power-of-two sizes normally take the pruned column passes (colfft.hip); the full rocFFT R2C/C2R +
+    separate roll-off path (used for other sizes) must give the same answer on the same input."""
+    rng = np.random.default_rng(81)
+    pos, batch, x = _random_problem(rng, 3, 400, 2, (2,), True)
+    from torch_nfft_amd import ops
+    ya = tn.nfft_adjoint(dev(x), dev(pos), dev(batch), bandwidth=16, cutoff=4)
+    yf = tn.nfft_forward(ya, dev(pos), dev(batch), cutoff=4)
+    monkeypatch.setenv("NFFT_HIP_NO_COLFFT", "1")
+    ops._ws_bytes_cache.clear()
+    ya2 = tn.nfft_adjoint(dev(x), dev(pos), dev(batch), bandwidth=16, cutoff=4)
+    yf2 = tn.nfft_forward(ya, dev(pos), dev(batch), cutoff=4)
+    ops._ws_bytes_cache.clear()
+    assert rel_l2(host(ya2), host(ya)) < 2e-6
+    assert rel_l2(host(yf2), host(yf)) < 2e-6
+    assert rel_l2(host(ya2), nfft_ref.nfft_adjoint(x, pos, batch, N=16, m=4)) < T1
+
+
+def test_plan_cache_follows_in_place_updates(tn):
+    """The host keeps one point plan keyed on tensor identity + version; editing pos in place must re-plan."""
+    from torch_nfft_amd import ops
+    rng = np.random.default_rng(91)
+    pos, _, x = _random_problem(rng, 2, 300, 1, (), False)
+    post, xt = dev(pos), dev(x)
+    ops.plan_cache_clear()
+    y1 = tn.nfft_adjoint(xt, post, None, bandwidth=16, cutoff=3)
+    h0 = ops.plan_cache_stats()["hits"]
+    y1b = tn.nfft_adjoint(xt, post, None, bandwidth=16, cutoff=3)
+    assert ops.plan_cache_stats()["hits"] == h0 + 1
+    assert rel_l2(host(y1b), host(y1)) < 1e-6
+    post.mul_(0.5)  # in-place: version counter changes
+    y2 = tn.nfft_adjoint(xt, post, None, bandwidth=16, cutoff=3)
+    assert rel_l2(host(y2), nfft_ref.nfft_adjoint(x, pos * 0.5, None, N=16, m=3)) < T1
+    ops.plan_cache_enabled(False)
+    y3 = tn.nfft_adjoint(xt, post, None, bandwidth=16, cutoff=3)
+    ops.plan_cache_enabled(True)
+    assert rel_l2(host(y3), host(y2)) < 1e-6
+
+
 def test_clustered_points_many_per_tile(tn):
     """All points inside one grid cell neighbourhood: stresses LDS accumulation order and the chunk sweep."""
     rng = np.random.default_rng(71)

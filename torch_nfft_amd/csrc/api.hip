@@ -84,8 +84,15 @@ struct Carve {
     PlanLayout L;
     int64_t n, B, C, Cr, total_planes, chunk_planes;
     int64_t half_cells;
-    int64_t off_plan, off_xs, off_grid, off_spec, off_work, work_bytes, total;
+    bool colfft;  // pruned column passes (colfft.hip) instead of the full dim-dimensional rocFFT transform
+    int64_t off_plan, off_xs, off_grid, off_spec, off_col, off_work, work_bytes, total;
 };
+
+bool colfft_enabled()
+{
+    const char *env = std::getenv("NFFT_HIP_NO_COLFFT");
+    return !(env && env[0] == '1');
+}
 
 // planes_per_col: 2 when a column owns a (re, im) pair of real planes, else 1
 int make_carve(const nfft_hip_problem *p, int planes_per_col, bool need_xs, FftKind kind, Carve &c)
@@ -99,7 +106,9 @@ int make_carve(const nfft_hip_problem *p, int planes_per_col, bool need_xs, FftK
     c.L = plan_layout(c.g, c.n, c.B);
     c.half_cells = (int64_t)(c.g.M / 2 + 1);
     for (int a = 0; a < 2; ++a) c.half_cells *= c.g.Ma[a];
-    const int64_t plane_bytes = c.g.cells * 4 + c.half_cells * 8;
+    c.colfft = colfft_supported(c.g) && colfft_enabled();
+    const FftKind fkind = c.colfft ? (kind == kR2C ? kR2CRows : kC2RRows) : kind;
+    const int64_t plane_bytes = c.g.cells * 4 + c.half_cells * 8 + (c.colfft ? colfft_scratch_bytes(c.g, 1) : 0);
     int64_t chunk = grid_budget_bytes() / plane_bytes;
     chunk -= chunk % planes_per_col;
     if (chunk < planes_per_col) chunk = planes_per_col;
@@ -109,12 +118,12 @@ int make_carve(const nfft_hip_problem *p, int planes_per_col, bool need_xs, FftK
     c.work_bytes = 0;
     if (c.total_planes > 0) {
         // plans for the full chunk and for the remainder chunk
-        int64_t w = fft_work_bytes(kind, c.g.dim, c.g.M, chunk);
+        int64_t w = fft_work_bytes(fkind, c.g.dim, c.g.M, chunk);
         if (w < 0) return NFFT_HIP_EFFT;
         c.work_bytes = w;
         const int64_t rem = c.total_planes % chunk;
         if (rem) {
-            w = fft_work_bytes(kind, c.g.dim, c.g.M, rem);
+            w = fft_work_bytes(fkind, c.g.dim, c.g.M, rem);
             if (w < 0) return NFFT_HIP_EFFT;
             if (w > c.work_bytes) c.work_bytes = w;
         }
@@ -124,6 +133,7 @@ int make_carve(const nfft_hip_problem *p, int planes_per_col, bool need_xs, FftK
     c.off_xs = o;   o = align_up(o + (need_xs ? c.n * c.Cr * 4 : 0), 256);
     c.off_grid = o; o = align_up(o + chunk * c.g.cells * 4, 256);
     c.off_spec = o; o = align_up(o + chunk * c.half_cells * 8, 256);
+    c.off_col = o;  o = align_up(o + (c.colfft ? colfft_scratch_bytes(c.g, chunk) : 0), 256);
     c.off_work = o; o = align_up(o + c.work_bytes, 256);
     c.total = o + 256;
     return 0;
@@ -251,8 +261,13 @@ static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64
         const int64_t np = std::min(c.chunk_planes, c.total_planes - p0);
         { StageTimer t(kStageZero, s); NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(np * c.g.cells * 4), s)); }
         { StageTimer t(kStageSpread, s); if (int rc = launch_spread(c.g, c.L, plan, xs, c.n, c.Cr, p0, np, grid, s)) return rc; }
-        { StageTimer t(kStageFft, s); if (int rc = fft_execute(kR2C, c.g.dim, c.g.M, np, grid, spec, work, c.work_bytes, s)) return rc; }
-        { StageTimer t(kStageDeconv, s); if (int rc = launch_deconv_adjoint(c.g, spec, c.C, x_is_complex, real_output, p0, np, y, s)) return rc; }
+        if (c.colfft) {
+            { StageTimer t(kStageFft, s); if (int rc = fft_execute(kR2CRows, c.g.dim, c.g.M, np, grid, spec, work, c.work_bytes, s)) return rc; }
+            { StageTimer t(kStageDeconv, s); if (int rc = launch_colfft_adjoint(c.g, spec, ws + c.off_col, c.chunk_planes, c.C, x_is_complex, real_output, p0, np, y, s)) return rc; }
+        } else {
+            { StageTimer t(kStageFft, s); if (int rc = fft_execute(kR2C, c.g.dim, c.g.M, np, grid, spec, work, c.work_bytes, s)) return rc; }
+            { StageTimer t(kStageDeconv, s); if (int rc = launch_deconv_adjoint(c.g, spec, c.C, x_is_complex, real_output, p0, np, y, s)) return rc; }
+        }
     }
     return 0;
 }
@@ -282,8 +297,13 @@ static int forward_impl(const nfft_hip_problem *p, const float *pos, const int64
     }
     for (int64_t p0 = 0; p0 < c.total_planes; p0 += c.chunk_planes) {
         const int64_t np = std::min(c.chunk_planes, c.total_planes - p0);
-        { StageTimer t(kStageDeconv, s); if (int rc = launch_deconv_forward(c.g, xhat, c.C, x_is_complex, real_output, p0, np, spec, s)) return rc; }
-        { StageTimer t(kStageFft, s); if (int rc = fft_execute(kC2R, c.g.dim, c.g.M, np, spec, grid, work, c.work_bytes, s)) return rc; }
+        if (c.colfft) {
+            { StageTimer t(kStageDeconv, s); if (int rc = launch_colfft_forward(c.g, xhat, ws + c.off_col, c.chunk_planes, c.C, x_is_complex, real_output, p0, np, spec, s)) return rc; }
+            { StageTimer t(kStageFft, s); if (int rc = fft_execute(kC2RRows, c.g.dim, c.g.M, np, spec, grid, work, c.work_bytes, s)) return rc; }
+        } else {
+            { StageTimer t(kStageDeconv, s); if (int rc = launch_deconv_forward(c.g, xhat, c.C, x_is_complex, real_output, p0, np, spec, s)) return rc; }
+            { StageTimer t(kStageFft, s); if (int rc = fft_execute(kC2R, c.g.dim, c.g.M, np, spec, grid, work, c.work_bytes, s)) return rc; }
+        }
         { StageTimer t(kStageInterp, s); if (int rc = launch_interp(c.g, c.L, plan, grid, c.n, c.Cr, p0, np, (float *)y, s)) return rc; }
     }
     return 0;

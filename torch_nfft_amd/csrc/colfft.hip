@@ -1,0 +1,390 @@
+// Pruned column FFT passes for the 3-D transforms (power-of-two M), fused with the roll-off.
+//
+// The reference transforms the whole (2N)^3 grid with cuFFT (csrc/cuda/core_cuda.cu:254-272, 432-450) and
+// then picks the N^3 band / zero-pads it (spectral_window_operations.cu:51-265).  Only N of the 2N
+// frequencies per axis are ever used, so after the contiguous axis-2 pass (rocFFT, real <-> half-complex
+// rows) the two strided passes run here on the band only:
+//
+//   adjoint:  S[u0][u1][k2]  --axis 1-->  T[u0][k1 in band+][k2 <= N/2]  --axis 0 + roll-off-->  y
+//   forward:  xhat --roll-off + Hermitian split + axis 0-->  T  --axis 1-->  S (zero for k2 > N/2)
+//
+// which cuts their HBM traffic to a quarter / an eighth of the full passes and removes the separate
+// roll-off kernels (adjoint) and the zero-fill of the padded spectrum (forward).  One workgroup transforms
+// a tile of NC adjacent k2-columns entirely in LDS (radix-2 DIF, bit-reversed output addressing), so
+// every global access is a run of NC * 8 contiguous bytes.
+//
+// "band+" is k in [-N/2, N/2]: the extra +N/2 row feeds the Hermitian mirror g_hat[-k] = conj(g_hat[k])
+// that reconstructs the k2 < 0 half of the spectrum from the stored k2 >= 0 half.
+#include "common.h"
+#include "kernels.h"
+
+namespace nfft {
+
+namespace {
+
+constexpr int kFftThreads = 256;
+
+struct ColGeom {
+    int M, logM, N, H;  // H = N/2
+    int Mh;             // M/2 + 1
+    int KC;             // kept k2 columns: 0..H
+    int NB;             // band+ rows: N + 1
+    int NC, logNC;      // columns per tile
+    float param;        // pi/3 * m / N^2  (phi_hat_inv exponent scale)
+};
+
+__device__ __forceinline__ float phi_hat_inv_f(int k, float param) { return expf((float)(k * k) * param); }
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// tw[j] = exp(-2 pi i j / M), j < M/2, evaluated in double
+__global__ void twiddle_kernel(float2 *tw, int M)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < M / 2) {
+        double s, c;
+        sincospi(2.0 * (double)j / (double)M, &s, &c);
+        tw[j] = make_float2((float)c, (float)-s);
+    }
+}
+
+// In-place radix-2 decimation-in-frequency FFT along the row index of buf[M][NC]; X[k] ends up in row brev(k).
+// INV selects exp(+2 pi i ...).  ltw is the twiddle table staged in LDS.
+template <bool INV>
+__device__ __forceinline__ void lds_fft(float2 *buf, const float2 *ltw, const ColGeom &cg, int tid)
+{
+    const int total = (cg.M / 2) << cg.logNC;
+    int shift = 0;
+    for (int h = cg.M / 2; h >= 1; h >>= 1, ++shift) {
+        __syncthreads();
+        for (int idx = tid; idx < total; idx += kFftThreads) {
+            const int col = idx & (cg.NC - 1);
+            const int t = idx >> cg.logNC;
+            const int j = t & (h - 1);
+            const int i = ((t - j) << 1) + j;
+            float2 *pa = buf + (i << cg.logNC) + col;
+            float2 *pb = buf + ((i + h) << cg.logNC) + col;
+            const float2 a = *pa, b = *pb;
+            float2 w = ltw[j << shift];
+            if (INV) w.y = -w.y;
+            *pa = make_float2(a.x + b.x, a.y + b.y);
+            *pb = cmul(make_float2(a.x - b.x, a.y - b.y), w);
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ int brev_row(int k, int logM) { return (int)(__brev((unsigned)k) >> (32 - logM)); }
+
+__device__ __forceinline__ void stage_twiddles(float2 *ltw, const float2 *__restrict__ tw, int M, int tid)
+{
+    for (int j = tid; j < M / 2; j += kFftThreads) ltw[j] = tw[j];
+}
+
+// ---- adjoint, axis 1:  S[plane][u0][u1][Mh] -> T[plane][u0][NB][KC] --------------------------------------
+__global__ void __launch_bounds__(kFftThreads)
+adj_axis1_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__restrict__ S, float2 *__restrict__ T)
+{
+    extern __shared__ float2 smem[];
+    float2 *ltw = smem;
+    float2 *buf = smem + cg.M / 2;
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x << cg.logNC;
+    const int u0 = blockIdx.y;
+    const int64_t plane = blockIdx.z;
+    stage_twiddles(ltw, tw, cg.M, tid);
+    const float2 *src = S + ((plane * cg.M + u0) * cg.M) * cg.Mh;
+    for (int idx = tid; idx < (cg.M << cg.logNC); idx += kFftThreads) {
+        const int col = idx & (cg.NC - 1), u1 = idx >> cg.logNC;
+        const int k2 = c0 + col;
+        buf[idx] = k2 < cg.KC ? src[(int64_t)u1 * cg.Mh + k2] : make_float2(0.f, 0.f);
+    }
+    lds_fft<false>(buf, ltw, cg, tid);
+    float2 *dst = T + ((plane * cg.M + u0) * cg.NB) * cg.KC;
+    for (int idx = tid; idx < (cg.NB << cg.logNC); idx += kFftThreads) {
+        const int col = idx & (cg.NC - 1), j1 = idx >> cg.logNC;
+        const int k2 = c0 + col;
+        if (k2 < cg.KC) {
+            const int k1 = (j1 - cg.H) & (cg.M - 1);
+            dst[(int64_t)j1 * cg.KC + k2] = buf[(brev_row(k1, cg.logM) << cg.logNC) + col];
+        }
+    }
+}
+
+// ---- adjoint, axis 0 + roll-off:  T -> y[b][N][N][N][C] ---------------------------------------------------
+// F = forward DFT of the real plane at (k0, k1, k2 >= 0).  g_hat (e^{+} convention) = conj(F); the k2 < 0 half
+// follows from g_hat[-k] = conj(g_hat[k]) = F[k].
+template <bool XCOMPLEX, bool REAL_OUT>
+__global__ void __launch_bounds__(kFftThreads)
+adj_axis0_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__restrict__ T, int64_t C, int64_t col0,
+                 void *__restrict__ yv)
+{
+    extern __shared__ float2 smem[];
+    float2 *ltw = smem;
+    float2 *buf = smem + cg.M / 2;
+    float2 *buf2 = buf + (cg.M << cg.logNC);
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x << cg.logNC;
+    const int j1 = blockIdx.y;
+    const int64_t col_local = blockIdx.z;  // (batch, column) pair inside this chunk of planes
+    stage_twiddles(ltw, tw, cg.M, tid);
+    const int64_t plane = XCOMPLEX ? col_local * 2 : col_local;
+    const int64_t pstride = (int64_t)cg.M * cg.NB * cg.KC;
+    const float2 *src = T + plane * pstride + (int64_t)j1 * cg.KC;
+    for (int idx = tid; idx < (cg.M << cg.logNC); idx += kFftThreads) {
+        const int col = idx & (cg.NC - 1), u0 = idx >> cg.logNC;
+        const int k2 = c0 + col;
+        const int64_t off = (int64_t)u0 * cg.NB * cg.KC + k2;
+        buf[idx] = k2 < cg.KC ? src[off] : make_float2(0.f, 0.f);
+        if (XCOMPLEX) buf2[idx] = k2 < cg.KC ? src[pstride + off] : make_float2(0.f, 0.f);
+    }
+    lds_fft<false>(buf, ltw, cg, tid);
+    if (XCOMPLEX) lds_fft<false>(buf2, ltw, cg, tid);
+
+    const int64_t colg = col0 + col_local;
+    const int64_t b = colg / C, c = colg - b * C;
+    const int H = cg.H, N = cg.N;
+    const int k1 = j1 - H;
+    const float f1 = phi_hat_inv_f(abs(k1), cg.param);
+    for (int idx = tid; idx < (cg.NB << cg.logNC); idx += kFftThreads) {
+        const int col = idx & (cg.NC - 1), j0 = idx >> cg.logNC;
+        const int k2 = c0 + col;
+        if (k2 >= cg.KC) continue;
+        const int k0 = j0 - H;
+        const int row = (brev_row(k0 & (cg.M - 1), cg.logM) << cg.logNC) + col;
+        const float2 fr = buf[row];
+        float2 fi = make_float2(0.f, 0.f);
+        if (XCOMPLEX) fi = buf2[row];
+        const float fac = phi_hat_inv_f(abs(k0), cg.param) * f1 * phi_hat_inv_f(k2, cg.param);
+        if (k0 < H && k1 < H && k2 < H) {
+            // direct: g_hat[k] = conj(F_re) + i conj(F_im)
+            const float re = fr.x + fi.y, im = -fr.y + fi.x;
+            const int64_t o = ((((b * N + (k0 + H)) * N + (k1 + H)) * N + (k2 + H)) * C) + c;
+            if (REAL_OUT) ((float *)yv)[o] = re * fac;
+            else ((float2 *)yv)[o] = make_float2(re * fac, im * fac);
+        }
+        if (k2 >= 1 && k0 > -H && k1 > -H) {
+            // mirror: g_hat[-k] = F_re + i F_im
+            const float re = fr.x - fi.y, im = fr.y + fi.x;
+            const int64_t o = ((((b * N + (H - k0)) * N + (H - k1)) * N + (H - k2)) * C) + c;
+            if (REAL_OUT) ((float *)yv)[o] = re * fac;
+            else ((float2 *)yv)[o] = make_float2(re * fac, im * fac);
+        }
+    }
+}
+
+// ---- forward, roll-off + Hermitian split + axis 0:  xhat -> T[plane][u0][NB][KC] ------------------------
+//   a[k] = xhat[b, k + N/2, c] * fac inside the band, 0 outside
+//   Re g = C2R( (a[-k] + conj(a[k])) / 2 ),  Im g = C2R( (a[-k] - conj(a[k])) / (2i) )     (e^{+} transforms)
+template <bool XCOMPLEX>
+__device__ __forceinline__ float2 band_value(const void *__restrict__ xhat, int64_t b, int64_t c, int64_t C, int N,
+                                             int H, int k0, int k1, int k2)
+{
+    if (k0 < -H || k0 >= H || k1 < -H || k1 >= H || k2 < -H || k2 >= H) return make_float2(0.f, 0.f);
+    const int64_t idx = (((b * N + (k0 + H)) * N + (k1 + H)) * N + (k2 + H)) * C + c;
+    if (XCOMPLEX) return ((const float2 *)xhat)[idx];
+    return make_float2(((const float *)xhat)[idx], 0.f);
+}
+
+template <bool XCOMPLEX>
+__global__ void __launch_bounds__(kFftThreads)
+fwd_axis0_kernel(ColGeom cg, const float2 *__restrict__ tw, const void *__restrict__ xhat, int64_t C, int ppc,
+                 int64_t plane0, float2 *__restrict__ T)
+{
+    extern __shared__ float2 smem[];
+    float2 *ltw = smem;
+    float2 *buf = smem + cg.M / 2;
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x << cg.logNC;
+    const int j1 = blockIdx.y;
+    const int64_t pl = blockIdx.z;
+    stage_twiddles(ltw, tw, cg.M, tid);
+    for (int idx = tid; idx < (cg.M << cg.logNC); idx += kFftThreads) buf[idx] = make_float2(0.f, 0.f);
+    __syncthreads();
+    const int64_t plane = plane0 + pl;
+    const int64_t colg = plane / ppc;
+    const int part = (int)(plane - colg * ppc);
+    const int64_t b = colg / C, c = colg - b * C;
+    const int H = cg.H;
+    const int k1 = j1 - H;
+    const float f1 = phi_hat_inv_f(abs(k1), cg.param);
+    for (int idx = tid; idx < (cg.NB << cg.logNC); idx += kFftThreads) {
+        const int col = idx & (cg.NC - 1), j0 = idx >> cg.logNC;
+        const int k2 = c0 + col;
+        if (k2 >= cg.KC) continue;
+        const int k0 = j0 - H;
+        const float2 ap = band_value<XCOMPLEX>(xhat, b, c, C, cg.N, H, k0, k1, k2);
+        const float2 am = band_value<XCOMPLEX>(xhat, b, c, C, cg.N, H, -k0, -k1, -k2);
+        const float fac = 0.5f * phi_hat_inv_f(abs(k0), cg.param) * f1 * phi_hat_inv_f(k2, cg.param);
+        float2 v;
+        if (part == 0) v = make_float2((am.x + ap.x) * fac, (am.y - ap.y) * fac);
+        else v = make_float2((am.y + ap.y) * fac, -(am.x - ap.x) * fac);
+        buf[((k0 & (cg.M - 1)) << cg.logNC) + col] = v;
+    }
+    lds_fft<true>(buf, ltw, cg, tid);
+    float2 *dst = T + pl * ((int64_t)cg.M * cg.NB * cg.KC) + (int64_t)j1 * cg.KC;
+    for (int idx = tid; idx < (cg.M << cg.logNC); idx += kFftThreads) {
+        const int col = idx & (cg.NC - 1), u0 = idx >> cg.logNC;
+        const int k2 = c0 + col;
+        if (k2 < cg.KC) dst[(int64_t)u0 * cg.NB * cg.KC + k2] = buf[(brev_row(u0, cg.logM) << cg.logNC) + col];
+    }
+}
+
+// ---- forward, axis 1:  T[plane][u0][NB][KC] -> S[plane][u0][u1][Mh]  (columns k2 >= KC are zero) ----------
+__global__ void __launch_bounds__(kFftThreads)
+fwd_axis1_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__restrict__ T, float2 *__restrict__ S)
+{
+    extern __shared__ float2 smem[];
+    float2 *ltw = smem;
+    float2 *buf = smem + cg.M / 2;
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x << cg.logNC;
+    const int u0 = blockIdx.y;
+    const int64_t plane = blockIdx.z;
+    float2 *dst = S + ((plane * cg.M + u0) * cg.M) * cg.Mh;
+    if (c0 >= cg.KC) {  // zero tail of the padded half spectrum
+        for (int idx = tid; idx < (cg.M << cg.logNC); idx += kFftThreads) {
+            const int col = idx & (cg.NC - 1), u1 = idx >> cg.logNC;
+            if (c0 + col < cg.Mh) dst[(int64_t)u1 * cg.Mh + c0 + col] = make_float2(0.f, 0.f);
+        }
+        return;
+    }
+    stage_twiddles(ltw, tw, cg.M, tid);
+    for (int idx = tid; idx < (cg.M << cg.logNC); idx += kFftThreads) buf[idx] = make_float2(0.f, 0.f);
+    __syncthreads();
+    const float2 *src = T + ((plane * cg.M + u0) * cg.NB) * cg.KC;
+    for (int idx = tid; idx < (cg.NB << cg.logNC); idx += kFftThreads) {
+        const int col = idx & (cg.NC - 1), j1 = idx >> cg.logNC;
+        const int k2 = c0 + col;
+        if (k2 < cg.KC) buf[(((j1 - cg.H) & (cg.M - 1)) << cg.logNC) + col] = src[(int64_t)j1 * cg.KC + k2];
+    }
+    lds_fft<true>(buf, ltw, cg, tid);
+    for (int idx = tid; idx < (cg.M << cg.logNC); idx += kFftThreads) {
+        const int col = idx & (cg.NC - 1), u1 = idx >> cg.logNC;
+        const int k2 = c0 + col;
+        if (k2 < cg.Mh) {
+            dst[(int64_t)u1 * cg.Mh + k2] =
+                k2 < cg.KC ? buf[(brev_row(u1, cg.logM) << cg.logNC) + col] : make_float2(0.f, 0.f);
+        }
+    }
+}
+
+ColGeom make_col_geom(const Geom &g, bool two_buffers)
+{
+    ColGeom cg;
+    cg.M = g.M;
+    cg.logM = 0;
+    while ((1 << cg.logM) < g.M) ++cg.logM;
+    cg.N = g.N;
+    cg.H = g.N / 2;
+    cg.Mh = g.M / 2 + 1;
+    cg.KC = cg.H + 1;
+    cg.NB = g.N + 1;
+    // tile of NC columns: M * NC * 8 bytes per buffer, at most ~64 KB so that two workgroups share a CU
+    int nc = 16;
+    while (nc > 1 && (int64_t)g.M * nc * 8 * (two_buffers ? 2 : 1) > 65536) nc >>= 1;
+    cg.NC = nc;
+    cg.logNC = 0;
+    while ((1 << cg.logNC) < nc) ++cg.logNC;
+    cg.param = 1.047197551196597746f * (float)g.m / ((float)g.N * (float)g.N);
+    return cg;
+}
+
+size_t col_lds_bytes(const ColGeom &cg, bool two_buffers)
+{
+    return (size_t)(cg.M / 2 + (int64_t)cg.M * cg.NC * (two_buffers ? 2 : 1)) * sizeof(float2);
+}
+
+// dynamic LDS above 64 KB has to be opted into per kernel
+template <typename K>
+void allow_lds(K kernel, size_t bytes)
+{
+    if (bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+} // namespace
+
+bool colfft_supported(const Geom &g)
+{
+    return g.dim == 3 && g.M >= 16 && g.M <= 1024 && (g.M & (g.M - 1)) == 0;
+}
+
+int64_t colfft_scratch_bytes(const Geom &g, int64_t nplanes)
+{
+    // T[plane][M][N+1][N/2+1] complex + twiddle table
+    return align_up(nplanes * (int64_t)g.M * (g.N + 1) * (g.N / 2 + 1) * 8, 256) + align_up((int64_t)g.M * 4, 256);
+}
+
+static float2 *twiddle_ptr(const Geom &g, int64_t nplanes, void *scratch)
+{
+    return (float2 *)((char *)scratch + align_up(nplanes * (int64_t)g.M * (g.N + 1) * (g.N / 2 + 1) * 8, 256));
+}
+
+int launch_colfft_adjoint(const Geom &g, const float2 *spec, void *scratch, int64_t scratch_planes, int64_t C,
+                          int x_is_complex, int real_output, int64_t plane0, int64_t nplanes, void *y,
+                          hipStream_t stream)
+{
+    if (nplanes <= 0) return 0;
+    float2 *T = (float2 *)scratch;
+    float2 *tw = twiddle_ptr(g, scratch_planes, scratch);
+    hipLaunchKernelGGL(twiddle_kernel, dim3((g.M / 2 + 255) / 256), dim3(256), 0, stream, tw, g.M);
+    {
+        const ColGeom cg = make_col_geom(g, false);
+        const dim3 grid((cg.KC + cg.NC - 1) / cg.NC, g.M, (unsigned)nplanes);
+        allow_lds(adj_axis1_kernel, col_lds_bytes(cg, false));
+        hipLaunchKernelGGL(adj_axis1_kernel, grid, dim3(kFftThreads), col_lds_bytes(cg, false), stream, cg, tw, spec, T);
+    }
+    {
+        const bool two = x_is_complex != 0;
+        const ColGeom cg = make_col_geom(g, two);
+        const int ppc = two ? 2 : 1;
+        const int64_t col0 = plane0 / ppc, ncols = nplanes / ppc;
+        const dim3 grid((cg.KC + cg.NC - 1) / cg.NC, cg.NB, (unsigned)ncols);
+        const size_t lds = col_lds_bytes(cg, two);
+        allow_lds(adj_axis0_kernel<true, true>, lds);
+        allow_lds(adj_axis0_kernel<true, false>, lds);
+        allow_lds(adj_axis0_kernel<false, true>, lds);
+        allow_lds(adj_axis0_kernel<false, false>, lds);
+        if (two) {
+            if (real_output) hipLaunchKernelGGL((adj_axis0_kernel<true, true>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, C, col0, y);
+            else hipLaunchKernelGGL((adj_axis0_kernel<true, false>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, C, col0, y);
+        } else {
+            if (real_output) hipLaunchKernelGGL((adj_axis0_kernel<false, true>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, C, col0, y);
+            else hipLaunchKernelGGL((adj_axis0_kernel<false, false>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, C, col0, y);
+        }
+    }
+    NFFT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_colfft_forward(const Geom &g, const void *xhat, void *scratch, int64_t scratch_planes, int64_t C,
+                          int x_is_complex, int real_output, int64_t plane0, int64_t nplanes, float2 *spec,
+                          hipStream_t stream)
+{
+    if (nplanes <= 0) return 0;
+    float2 *T = (float2 *)scratch;
+    float2 *tw = twiddle_ptr(g, scratch_planes, scratch);
+    hipLaunchKernelGGL(twiddle_kernel, dim3((g.M / 2 + 255) / 256), dim3(256), 0, stream, tw, g.M);
+    const ColGeom cg = make_col_geom(g, false);
+    const size_t lds = col_lds_bytes(cg, false);
+    const int ppc = real_output ? 1 : 2;
+    allow_lds(fwd_axis0_kernel<true>, lds);
+    allow_lds(fwd_axis0_kernel<false>, lds);
+    allow_lds(fwd_axis1_kernel, lds);
+    {
+        const dim3 grid((cg.KC + cg.NC - 1) / cg.NC, cg.NB, (unsigned)nplanes);
+        if (x_is_complex) hipLaunchKernelGGL((fwd_axis0_kernel<true>), grid, dim3(kFftThreads), lds, stream, cg, tw, xhat, C, ppc, plane0, T);
+        else hipLaunchKernelGGL((fwd_axis0_kernel<false>), grid, dim3(kFftThreads), lds, stream, cg, tw, xhat, C, ppc, plane0, T);
+    }
+    {
+        const dim3 grid((cg.Mh + cg.NC - 1) / cg.NC, g.M, (unsigned)nplanes);
+        hipLaunchKernelGGL(fwd_axis1_kernel, grid, dim3(kFftThreads), lds, stream, cg, tw, T, spec);
+    }
+    NFFT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+} // namespace nfft

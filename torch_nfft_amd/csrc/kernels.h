@@ -28,10 +28,22 @@ int launch_deconv_forward(const Geom &g, const void *xhat, int64_t C, int x_is_c
                           int64_t plane0, int64_t nplanes, float2 *spec, hipStream_t stream);
 
 // fft.cpp (rocFFT, plans cached per (kind, dim, M, batch) and device)
-enum FftKind { kR2C = 0, kC2R = 1 };
+// kR2C / kC2R: full dim-dimensional real transforms of every plane; k*Rows: 1-D transforms of every grid row
+// (last axis only), used together with the pruned column passes of colfft.hip
+enum FftKind { kR2C = 0, kC2R = 1, kR2CRows = 2, kC2RRows = 3 };
 int64_t fft_work_bytes(FftKind kind, int dim, int M, int64_t nplanes);
 int fft_execute(FftKind kind, int dim, int M, int64_t nplanes, void *in, void *out, void *work, int64_t work_bytes,
                 hipStream_t stream);
+
+// colfft.hip: pruned strided passes over axes 1 and 0 fused with the roll-off (3-D, power-of-two M)
+bool colfft_supported(const Geom &g);
+int64_t colfft_scratch_bytes(const Geom &g, int64_t nplanes);
+int launch_colfft_adjoint(const Geom &g, const float2 *spec, void *scratch, int64_t scratch_planes, int64_t C,
+                          int x_is_complex, int real_output, int64_t plane0, int64_t nplanes, void *y,
+                          hipStream_t stream);
+int launch_colfft_forward(const Geom &g, const void *xhat, void *scratch, int64_t scratch_planes, int64_t C,
+                          int x_is_complex, int real_output, int64_t plane0, int64_t nplanes, float2 *spec,
+                          hipStream_t stream);
 
 // api.hip: optional per-stage GPU timing with HIP events on the caller's stream (nfft_hip_profile_*)
 enum Stage { kStagePlan = 0, kStageGather, kStageZero, kStageSpread, kStageFft, kStageDeconv, kStageInterp, kNumStages };
