@@ -8,8 +8,11 @@
 //   * the NP = TC + 2m+1 planes a chunk needs are resident in LDS: between chunks the 2m+1 still-needed
 //     planes slide down and only TC new ones are fetched (coalesced row loads), so every plane of a pencil
 //     is read from HBM/L2 once per segment;
-//   * one wave per point, lanes = (l1, l2) taps, axis-0 taps unrolled; the 64 partial sums are reduced
-//     with DPP row shifts/broadcasts (no LDS traffic) and the wave writes 64 outputs at a time.
+//   * one LANE per point: a lane walks the (2m+2)^d window of its own point -- per row of the window
+//     ceil((2m+5)/4) aligned ds_read_b128 (the axis-2 weights are evaluated on the aligned positions and are
+//     zero outside the window) and 4 FMAs per read; the axis-0/1 weights are one v_exp_f32 per row/plane.  No
+//     cross-lane reduction, no per-point scalar broadcasts: ~40 wave instructions per point instead of ~120
+//     for the tap-per-lane layout this kernel started with.
 // g is held as real planes (re and im of a complex grid are separate planes = separate real columns).
 #include "common.h"
 #include "kernels.h"
@@ -17,37 +20,39 @@
 
 namespace nfft {
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_zero(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
-}
-
-// Sum over the 64 lanes; the total ends up in lane 63.
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
-{
-    v += dpp_zero<0x111, 0xf>(v);  // row_shr:1
-    v += dpp_zero<0x112, 0xf>(v);  // row_shr:2
-    v += dpp_zero<0x114, 0xf>(v);  // row_shr:4
-    v += dpp_zero<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of every row holds the row sum
-    v += dpp_zero<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
-    v += dpp_zero<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
-template <int DIM>
-constexpr int interp_threads() { return DIM == 3 ? 512 : 256; }
+// Geometry of the gather kernel.  It shares the point plan (pencils, chunks of TC planes) with the spreading
+// kernel but keeps 4-byte cells and rows padded to a multiple of 4 floats so that a lane can fetch its
+// 2m+2 taps of a row with aligned ds_read_b128.
+template <int DIM, int W>
+struct GatherCfg {
+    static constexpr TileCfg tc = tile_cfg(DIM, W);
+    static constexpr int T1 = tc.T1, T2 = tc.T2, TC = tc.TC;
+    static constexpr int W0 = DIM == 3 ? W : 1;
+    static constexpr int W1 = DIM >= 2 ? W : 1;
+    static constexpr int M0OFF = DIM == 3 ? (W / 2 - 1) : 0;
+    static constexpr int NP = TC + W0 - 1;
+    static constexpr int P1 = T1 + W1 - 1;
+    static constexpr int P2 = T2 + W - 1;
+    static constexpr int NR = (W + 3 + 3) / 4;            // aligned 16-byte reads covering any 2m+2 window
+    static constexpr int S2 = (P2 + 3 + 3) / 4 * 4;       // row stride (floats): room for the aligned over-read
+    static constexpr int S0 = P1 * S2;
+    static constexpr int CELLS = NP * S0;
+    static constexpr int NT = DIM == 3 ? 512 : 256;
+    static constexpr int NWAVES = NT / 64;
+    static_assert(CELLS * 4 <= 160 * 1024, "LDS budget");
+};
 
 template <int DIM, int W>
-__global__ void __launch_bounds__((interp_threads<DIM>()))
+__global__ void __launch_bounds__((GatherCfg<DIM, W>::NT))
 interp_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__restrict__ perm,
               const float *__restrict__ spos, const float *__restrict__ grid, const int Cr, const int plane0,
               float *__restrict__ yr)
 {
-    using C = TapCfg<DIM, W>;
-    constexpr int NT = interp_threads<DIM>();
-    constexpr int NWAVES = NT / 64;
-    __shared__ float planes[C::CELLS];
+    using C = GatherCfg<DIM, W>;
+    constexpr int NT = C::NT;
+    constexpr int NWAVES = C::NWAVES;
+    __shared__ float4 planes4[C::CELLS / 4];
+    float *const planes = (float *)planes4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -72,11 +77,6 @@ interp_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__r
     const float sc = win_exp_scale(m);
     float norm = win_norm(m);
     norm = DIM == 3 ? norm * norm * norm : (DIM == 2 ? norm * norm : norm);
-
-    LaneTaps<DIM, W> taps;
-    taps.init(lane, m);
-    const float c0 = (float)(m - lane);
-
     const float *const gplane = grid + (int64_t)plane_local * g.cells;
 
     // Resident plane p holds the (unwrapped) grid plane base_z + p; planes [0, have) are valid.
@@ -113,45 +113,78 @@ interp_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__r
         __syncthreads();
         const int tb0 = k * C::TC;
 
-        const int len = (e - s + NWAVES - 1) / NWAVES;
-        const int a = s + wave * len;
-        const int bnd = min(e, a + len);
-        for (int j0 = a; j0 < bnd; j0 += 64) {
-            const int cnt = min(64, bnd - j0);
-            PointPrep<DIM, W> pp;
-            if (lane < cnt) pp.load(g, spos, (int64_t)j0 + lane, tb0, tb1, tb2);
-            else pp.clear();
-            float result = 0.0f;
-            for (int q = 0; q < cnt; ++q) {
-                const float f1 = readlane_f(pp.f1, q), f2 = readlane_f(pp.f2, q);
-                const float *const origin = planes + readlane_i(pp.base, q);
-                float ps0[C::W0];
-                if (DIM == 3) {
-                    const float d0 = readlane_f(pp.f0, q) + c0;
-                    const float psi0 = __builtin_amdgcn_exp2f(sc * d0 * d0);
+        // one lane per point: each lane walks the (2m+2)^d window of its own point
+        // full 64-point batches are dealt round-robin to the waves (only the chunk's last batch is partial)
+        for (int j0 = s + wave * 64; j0 < e; j0 += NWAVES * 64) {
+            const int j = j0 + lane;
+            if (j >= e) continue;
+            int c0 = 0, c1 = 0, c2 = 0;
+            float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+            if (DIM == 3) {
+                split_cell(spos[(int64_t)j * 3 + 0], g.M, c0, f0);
+                split_cell(spos[(int64_t)j * 3 + 1], g.M, c1, f1);
+                split_cell(spos[(int64_t)j * 3 + 2], g.M, c2, f2);
+            } else if (DIM == 2) {
+                split_cell(spos[(int64_t)j * 2 + 0], g.M, c1, f1);
+                split_cell(spos[(int64_t)j * 2 + 1], g.M, c2, f2);
+            } else {
+                split_cell(spos[j], g.M, c2, f2);
+            }
+            const int col = c2 - tb2;       // window origin column inside the padded row
+            const int sh = col & 3;         // its offset from the 16-byte boundary below it
+            // axis-2 weights on the aligned positions; zero outside the window so the over-read is harmless
+            float w2[4 * C::NR];
 #pragma unroll
-                    for (int l0 = 0; l0 < C::W0; ++l0) ps0[l0] = readlane_f(psi0, l0);
-                } else {
-                    ps0[0] = 1.0f;
-                }
-                float acc = 0.0f;
+            for (int q = 0; q < 4 * C::NR; ++q) {
+                const int l2 = q - sh;
+                const float t = f2 + (float)(m - l2);
+                const float v = __builtin_amdgcn_exp2f(sc * t * t);
+                w2[q] = (l2 >= 0 && l2 < W) ? v : 0.0f;
+            }
+            const float4 *row0 = (const float4 *)(planes + (c0 - tb0) * C::S0 + (c1 - tb1) * C::S2 + (col - sh));
+            // axis-1 weights (one v_exp_f32 each, reused by every plane)
+            float w1[C::W1];
 #pragma unroll
-                for (int p = 0; p < C::PASSES; ++p) {
-                    if (taps.valid[p]) {
-                        const float d1 = f1 + taps.c1[p], d2 = f2 + taps.c2[p];
-                        const float r2 = DIM >= 2 ? fmaf(d1, d1, d2 * d2) : d2 * d2;
-                        const float w12 = __builtin_amdgcn_exp2f(sc * r2);
-                        const float *src = origin + taps.off[p];
-                        float part = 0.0f;
+            for (int l1 = 0; l1 < C::W1; ++l1) {
+                const float t1 = f1 + (float)(m - l1);
+                w1[l1] = DIM >= 2 ? __builtin_amdgcn_exp2f(sc * t1 * t1) : 1.0f;
+            }
+            // Rows are processed RB at a time with all their reads in flight and two accumulation chains per
+            // row: the loop is LDS-latency bound otherwise (one wave-wide ds_read_b128 -> wait -> 4 dependent FMAs).
+            constexpr int RB = C::W1 % 2 == 0 ? 2 : 1;  // more rows in flight cost occupancy (152 VGPRs at 5 rows)
+            float acc0 = 0.0f;
+            for (int l0 = 0; l0 < C::W0; ++l0) {
+                const float4 *rowp = row0 + l0 * (C::S0 / 4);
+                float acc1a = 0.0f, acc1b = 0.0f;
 #pragma unroll
-                        for (int l0 = 0; l0 < C::W0; ++l0) part = fmaf(ps0[l0], src[l0 * C::S0], part);
-                        acc = fmaf(w12, part, acc);
+                for (int l1 = 0; l1 < C::W1; l1 += RB) {
+                    float4 v[RB][C::NR];
+#pragma unroll
+                    for (int r = 0; r < RB; ++r)
+#pragma unroll
+                        for (int q = 0; q < C::NR; ++q) v[r][q] = rowp[(l1 + r) * (C::S2 / 4) + q];
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) {
+                        float r0 = 0.0f, r1 = 0.0f;
+#pragma unroll
+                        for (int q = 0; q < C::NR; ++q) {
+                            r0 = fmaf(w2[4 * q + 0], v[r][q].x, r0);
+                            r1 = fmaf(w2[4 * q + 1], v[r][q].y, r1);
+                            r0 = fmaf(w2[4 * q + 2], v[r][q].z, r0);
+                            r1 = fmaf(w2[4 * q + 3], v[r][q].w, r1);
+                        }
+                        if (r & 1) acc1b = fmaf(w1[l1 + r], r0 + r1, acc1b);
+                        else acc1a = fmaf(w1[l1 + r], r0 + r1, acc1a);
                     }
                 }
-                const float total = readlane_f(wave_sum_to_lane63(acc), 63);
-                if (lane == q) result = total;
+                float p0 = 1.0f;
+                if (DIM == 3) {
+                    const float t0 = f0 + (float)(m - l0);
+                    p0 = __builtin_amdgcn_exp2f(sc * t0 * t0);
+                }
+                acc0 = fmaf(p0, acc1a + acc1b, acc0);
             }
-            if (lane < cnt) yr[(int64_t)perm[j0 + lane] * Cr + cr] = result * norm;
+            yr[(int64_t)perm[j] * Cr + cr] = acc0 * norm;
         }
     }
 }
@@ -161,7 +194,7 @@ static int launch_interp_t(const Geom &g, const int *to, const int *perm, const 
                            int64_t Cr, int64_t plane0, int64_t nplanes, float *yr, hipStream_t stream)
 {
     const dim3 blocks((unsigned)(g.nta[1] * g.nta[2] * g.nseg), (unsigned)nplanes);
-    hipLaunchKernelGGL((interp_kernel<DIM, W>), blocks, dim3(interp_threads<DIM>()), 0, stream, g, to, perm, spos, grid, (int)Cr,
+    hipLaunchKernelGGL((interp_kernel<DIM, W>), blocks, dim3(GatherCfg<DIM, W>::NT), 0, stream, g, to, perm, spos, grid, (int)Cr,
                        (int)plane0, yr);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
