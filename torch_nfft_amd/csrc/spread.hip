@@ -82,19 +82,21 @@ spread_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *_
     // remaining batches are a linear LDS move.  Batch b only reads what batch b+1 will overwrite.
     auto retire = [&](int shift) {
         __syncthreads();
-        const int rows = shift * C::P1;
-        for (int row = wave; row < rows; row += NWAVES) {
-            const int p = row / C::P1;
-            const int r = row - p * C::P1;
-            const int64_t gz = DIM == 3 ? wrap(base_z + p, g.Ma[0]) : 0;
-            const int64_t g1 = DIM >= 2 ? wrap(tb1 - m + r, g.Ma[1]) : 0;
-            float *const grow = gplane + (gz * g.Ma[1] + g1) * g.Ma[2];
-            for (int c = lane; c < C::S2; c += 64) {
-                const int idx = row * C::S2 + c;
-                const double v = acc[idx];
-                const int src = idx + shift * C::S0;
-                acc[idx] = src < C::CELLS ? acc[src] : 0.0;
-                if (v != 0.0) atomicAdd(grow + wrap_near(tb2 - m + c, g.Ma[2]), (float)v);
+        // Batch 0: all 64 lanes of every wave instruction carry a cell (a padded row is S2 = T2 + 2m+2 cells, so
+        // consecutive lanes run across row ends): the memory side accepts roughly one float-atomic wave
+        // instruction per 50 ns per CU whatever its lane count, so fewer, fuller instructions matter.
+        for (int idx = tid; idx < shift * C::S0; idx += NT) {
+            const int p = idx / C::S0;
+            const int rem = idx - p * C::S0;
+            const int r = rem / C::S2;
+            const int c = rem - r * C::S2;
+            const double v = acc[idx];
+            const int src = idx + shift * C::S0;
+            acc[idx] = src < C::CELLS ? acc[src] : 0.0;
+            if (v != 0.0) {
+                const int64_t gz = DIM == 3 ? wrap_near(base_z + p, g.Ma[0]) : 0;
+                const int64_t g1 = DIM >= 2 ? wrap_near(tb1 - m + r, g.Ma[1]) : 0;
+                atomicAdd(gplane + (gz * g.Ma[1] + g1) * g.Ma[2] + wrap_near(tb2 - m + c, g.Ma[2]), (float)v);
             }
         }
         for (int lo = shift * C::S0; lo < C::CELLS; lo += shift * C::S0) {
