@@ -115,6 +115,29 @@ int nfft_hip_spread(const nfft_hip_problem *p, const void *plan, const float *xr
 int nfft_hip_interpolate(const nfft_hip_problem *p, const void *plan, const float *grid,
                          int64_t real_columns, float *yr, void *stream);
 
+/* ---- fast summation and kernel coefficients ----
+ * nfft_fastsum of the reference (csrc/cuda/core_cuda.cu:535-852) is adjoint(sources) -> spectral multiply ->
+ * forward(targets); its spectral step (spectral_window_operations.cu:269-402: g_hat *= coeffs * phi_hat_inv^2 on
+ * the band, 0 elsewhere) is, on the band spectrum that nfft_hip_adjoint returns and nfft_hip_forward consumes,
+ * the plain product below.  yhat [B, N^dim, C] complex64 in place; coeffs [N^dim] float32 or complex64. */
+int nfft_hip_spectral_multiply(void *yhat, const void *coeffs, int coeffs_are_complex, int64_t batch_size,
+                               int64_t band_size, int64_t num_columns, void *stream);
+
+/* Coefficient set-up (csrc/cuda/kernel_coeffs.cu, drivers core_cuda.cu:855-1064).  Outputs are [N]^dim
+ * arrays, index l + N/2 on every axis.
+ *   gaussian_analytic_coeffs      float32:  prod_d sqrt(pi) sigma exp(-sigma^2 pi^2 l_d^2)      (kernel_coeffs.cu:6-30)
+ *   interpolation_grid            float32 [N^dim, dim] (radial = 0) or [N^dim] norms (radial = 1)  (:76-123)
+ *   gaussian_interpolated_coeffs  complex64: fftshift(FFT(ifftshift(K(k/N - 1/2)))) / N^dim, K Gaussian (p < 0) or
+ *                                 Gaussian clipped outside radius 1/2 (p == 0); only p <= 0, eps == 0  (:33-73, :179-202)
+ *   interpolated_kernel_coeffs    complex64: the same recipe on user samples (float32 or complex64)  (:126-202) */
+int nfft_hip_gaussian_analytic_coeffs(double sigma, int64_t N, int32_t dim, float *coeffs, void *stream);
+int nfft_hip_interpolation_grid(int64_t N, int32_t dim, int radial, float *grid, void *stream);
+int64_t nfft_hip_coeffs_workspace_bytes(int64_t N, int32_t dim);
+int nfft_hip_gaussian_interpolated_coeffs(double sigma, int64_t N, int32_t dim, int64_t p, double eps, void *coeffs,
+                                          void *workspace, int64_t workspace_bytes, void *stream);
+int nfft_hip_interpolated_kernel_coeffs(const void *grid_values, int values_are_complex, int64_t N, int32_t dim,
+                                        void *coeffs, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ---- measurement hooks (bench.py) ----
  * When enabled, nfft_hip_adjoint / nfft_hip_forward bracket each stage with HIP events recorded on the
  * caller's stream.  nfft_hip_profile_collect waits for the recorded events and returns, per stage, the

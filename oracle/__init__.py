@@ -14,6 +14,7 @@ Contents
                  roll-off) -- restates ``csrc/cuda/spatial_window_operations.cu``,
                  ``csrc/cuda/spectral_window_operations.cu`` and the drivers in
                  ``csrc/cuda/core_cuda.cu:144-531``.
+``coeffs_ref.py`` float64 restatement of the kernel-coefficient recipes (csrc/cuda/kernel_coeffs.cu).
 ``ndft_c.c``     plain-C (OpenMP) exact NDFT used for the CPU baseline timing;
                  built into ``oracle/_build/libndft_oracle.so`` by ``oracle/Makefile``.
 ``make_golden.py``  imports the reference's own ``torch_nfft/ndft.py`` (CPU,

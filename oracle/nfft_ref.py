@@ -131,3 +131,21 @@ def nfft_forward(x, pos, batch=None, m=3, real_output=False):
             y[:, c] += w * g[(bvec, c) + tuple(idx)]
     y = y.reshape((n,) + cols)
     return y.real.copy() if real_output else y
+
+
+def nfft_fastsum(x, coeffs, sources, targets=None, source_batch=None, target_batch=None, batch=None, m=3):
+    """Restates nfft_fastsum_cuda (core_cuda.cu:535-852): spreading of the sources, inverse FFT, spectral
+    multiply g_hat *= coeffs * phi_hat_inv^2 on the band / 0 elsewhere (spectral_window_operations.cu:269-402),
+    forward FFT, interpolation at the targets; real part when x is real."""
+    if targets is None:
+        targets, target_batch = sources, source_batch
+    if batch is not None:
+        source_batch = target_batch = batch
+    x = np.asarray(x)
+    coeffs = np.asarray(coeffs)
+    N = coeffs.shape[0]
+    d = coeffs.ndim
+    y = nfft_adjoint(x, sources, source_batch, N=N, m=m)                     # band spectrum incl. one phi_hat_inv
+    y = y * coeffs.reshape((1,) + coeffs.shape + (1,) * (y.ndim - 1 - d))
+    out = nfft_forward(y, targets, target_batch, m=m)                         # applies the second phi_hat_inv
+    return out if np.iscomplexobj(x) else out.real

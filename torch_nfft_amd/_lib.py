@@ -25,6 +25,12 @@ SYMBOLS = (
     "nfft_hip_plan_points",
     "nfft_hip_spread",
     "nfft_hip_interpolate",
+    "nfft_hip_spectral_multiply",
+    "nfft_hip_gaussian_analytic_coeffs",
+    "nfft_hip_interpolation_grid",
+    "nfft_hip_coeffs_workspace_bytes",
+    "nfft_hip_gaussian_interpolated_coeffs",
+    "nfft_hip_interpolated_kernel_coeffs",
     "nfft_hip_profile_enable",
     "nfft_hip_profile_collect",
 )
@@ -81,6 +87,19 @@ def load():
     lib.nfft_hip_spread.restype = ci
     lib.nfft_hip_interpolate.argtypes = [P, vp, vp, i64, vp, vp]
     lib.nfft_hip_interpolate.restype = ci
+    lib.nfft_hip_spectral_multiply.argtypes = [vp, vp, ci, i64, i64, i64, vp]
+    lib.nfft_hip_spectral_multiply.restype = ci
+    lib.nfft_hip_gaussian_analytic_coeffs.argtypes = [ctypes.c_double, i64, ctypes.c_int32, vp, vp]
+    lib.nfft_hip_gaussian_analytic_coeffs.restype = ci
+    lib.nfft_hip_interpolation_grid.argtypes = [i64, ctypes.c_int32, ci, vp, vp]
+    lib.nfft_hip_interpolation_grid.restype = ci
+    lib.nfft_hip_coeffs_workspace_bytes.argtypes = [i64, ctypes.c_int32]
+    lib.nfft_hip_coeffs_workspace_bytes.restype = i64
+    lib.nfft_hip_gaussian_interpolated_coeffs.argtypes = [ctypes.c_double, i64, ctypes.c_int32, i64, ctypes.c_double,
+                                                          vp, vp, i64, vp]
+    lib.nfft_hip_gaussian_interpolated_coeffs.restype = ci
+    lib.nfft_hip_interpolated_kernel_coeffs.argtypes = [vp, ci, i64, ctypes.c_int32, vp, vp, i64, vp]
+    lib.nfft_hip_interpolated_kernel_coeffs.restype = ci
     lib.nfft_hip_profile_enable.argtypes = [ci]
     lib.nfft_hip_profile_enable.restype = None
     lib.nfft_hip_profile_collect.argtypes = [vp, vp, ci]

@@ -66,9 +66,14 @@ int get_plan(FftKind kind, int dim, int M, int64_t nplanes, PlanEntry &out)
     size_t batch = (size_t)nplanes;
     if (rows)  // one 1-D transform per grid row: planes * M^(dim-1) rows
         for (int a = 1; a < dim; ++a) batch *= (size_t)M;
-    rocfft_status st = rocfft_plan_create(&e.plan, rocfft_placement_notinplace,
-                                          fwd ? rocfft_transform_type_real_forward : rocfft_transform_type_real_inverse,
-                                          rocfft_precision_single, rows ? 1 : (size_t)dim, lengths, batch, nullptr);
+    rocfft_status st;
+    if (kind == kC2CForward)
+        st = rocfft_plan_create(&e.plan, rocfft_placement_inplace, rocfft_transform_type_complex_forward,
+                                rocfft_precision_single, (size_t)dim, lengths, batch, nullptr);
+    else
+        st = rocfft_plan_create(&e.plan, rocfft_placement_notinplace,
+                                fwd ? rocfft_transform_type_real_forward : rocfft_transform_type_real_inverse,
+                                rocfft_precision_single, rows ? 1 : (size_t)dim, lengths, batch, nullptr);
     if (st != rocfft_status_success) {
         set_error(std::string("Failed to create rocFFT plan: ") + status_name(st));
         return 3;

@@ -30,7 +30,8 @@ int launch_deconv_forward(const Geom &g, const void *xhat, int64_t C, int x_is_c
 // fft.cpp (rocFFT, plans cached per (kind, dim, M, batch) and device)
 // kR2C / kC2R: full dim-dimensional real transforms of every plane; k*Rows: 1-D transforms of every grid row
 // (last axis only), used together with the pruned column passes of colfft.hip
-enum FftKind { kR2C = 0, kC2R = 1, kR2CRows = 2, kC2RRows = 3 };
+// kC2CForward: in-place complex forward transform of an N^dim array (coefficient set-up, coeffs.hip)
+enum FftKind { kR2C = 0, kC2R = 1, kR2CRows = 2, kC2RRows = 3, kC2CForward = 4 };
 int64_t fft_work_bytes(FftKind kind, int dim, int M, int64_t nplanes);
 int fft_execute(FftKind kind, int dim, int M, int64_t nplanes, void *in, void *out, void *work, int64_t work_bytes,
                 hipStream_t stream);

@@ -1,5 +1,5 @@
-"""Public API: ``nfft_adjoint`` / ``nfft_forward`` with the reference's signatures and autograd
-behaviour (reference: ``torch_nfft/nfft.py:11-58``).
+"""Public API: ``nfft_adjoint`` / ``nfft_forward`` / ``nfft_fastsum`` with the reference's signatures and
+autograd behaviour (reference: ``torch_nfft/nfft.py:11-179``).
 
 Adjoint and forward are each other's transposes, so each one's backward is the other
 (``nfft.py:22-28, 48-54``); there is no gradient w.r.t. the points.
@@ -50,3 +50,43 @@ class NfftForwardFunction(torch.autograd.Function):
 def nfft_forward(x, pos, batch=None, cutoff=3, real_output=False):
     """y[i, ...] ~= sum_k x[batch[i], k+N/2, ...] exp(-2 pi i k.pos[i]),  N = x.size(1)."""
     return NfftForwardFunction.apply(x, pos, batch, cutoff, real_output)
+
+
+class NfftFastsumFunction(torch.autograd.Function):
+    """y = K x with the trigonometric kernel matrix K_ij = sum_l coeffs[l] exp(2 pi i l.(source_j - target_i)).
+    Linear in x; its transpose swaps sources and targets (reference: nfft.py:62-88)."""
+
+    @staticmethod
+    def forward(ctx, x, coeffs, sources, targets, source_batch, target_batch, cutoff):
+        assert not coeffs.requires_grad, \
+            "NfftFastsum: Gradient computation w.r.t. coefficients is not possible"
+        assert not sources.requires_grad and not targets.requires_grad, \
+            "NfftFastsum: Gradient computation w.r.t. sources and targets is not possible"
+        assert source_batch is None or not source_batch.requires_grad, \
+            "NfftFastsum: Gradient computation w.r.t. batches is not possible"
+        assert target_batch is None or not target_batch.requires_grad, \
+            "NfftFastsum: Gradient computation w.r.t. batches is not possible"
+        y = ops.nfft_fastsum(sources, targets, x, coeffs, source_batch, target_batch, cutoff)
+        ctx.save_for_backward(sources, targets, coeffs, source_batch, target_batch)
+        ctx.cutoff = cutoff
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        sources, targets, coeffs, source_batch, target_batch = ctx.saved_tensors
+        dx = ops.nfft_fastsum(targets, sources, dy, coeffs, target_batch, source_batch, ctx.cutoff)
+        return dx, None, None, None, None, None, None
+
+
+def nfft_fastsum(x, coeffs, sources, targets=None, source_batch=None, target_batch=None, /, batch=None, cutoff=3):
+    """Fast multiplication with a trigonometric kernel matrix (reference: nfft.py:91-179).
+
+    ``y = nfft_fastsum(x, coeffs, sources[, targets][, source_batch, target_batch][, batch=...][, cutoff=...])``;
+    ``coeffs`` is a ``[N]*d`` tensor holding b_l at index ``l + N/2``; a real ``x`` gives a real ``y``."""
+    if targets is None:
+        targets = sources
+        target_batch = source_batch
+    if batch is not None:
+        source_batch = batch
+        target_batch = batch
+    return NfftFastsumFunction.apply(x, coeffs, sources, targets, source_batch, target_batch, cutoff)

@@ -178,6 +178,122 @@ def nfft_forward(pos, x, batch, m, real_output):
     return y
 
 
+def nfft_fastsum(sources, targets, x, coeffs, source_batch, target_batch, m):
+    """torch_nfft::nfft_fastsum(Tensor sources, Tensor targets, Tensor x, Tensor coeffs, Tensor? source_batch,
+    Tensor? target_batch, int m) -> Tensor   (csrc/core.cpp:108-121; driver core_cuda.cu:535-852).
+
+    y = Re?[ forward_targets( coeffs * adjoint_sources(x) ) ]: the reference fuses the three steps on the
+    oversampled grid; on the band spectrum they are exactly adjoint -> product with coeffs -> forward.  When
+    sources and targets are the same tensor the point plan is shared (core_cuda.cu:552-564)."""
+    if not x.is_cuda:
+        raise RuntimeError("torch_nfft.nfft_fastsum is currently only implemented for GPU tensors")
+    if not coeffs.is_cuda:
+        raise RuntimeError("coeffs must be CUDA tensor")
+    dim = sources.size(1) if sources.dim() == 2 else -1
+    _assert_input(coeffs.dim() == dim)  # core_cuda.cu:585-590
+    N = coeffs.size(0)
+    for d in range(1, dim):
+        _assert_input(coeffs.size(d) == N)
+    real_coeffs = _is_real(coeffs)
+    _assert_input(targets.dim() == 2 and targets.size(1) == dim)
+    real_input = not x.is_complex()
+    yhat = nfft_adjoint(sources, x, source_batch, N, m, 0)
+    B = yhat.size(0)
+    C = yhat.numel() // (B * N ** dim) if yhat.numel() else 0
+    if yhat.numel():
+        coeffs_c = coeffs.contiguous()
+        with torch.cuda.device(x.device):
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            _lib.check(_lib.load().nfft_hip_spectral_multiply(_ptr(yhat), _ptr(coeffs_c), 0 if real_coeffs else 1, B,
+                                                              N ** dim, C, ctypes.c_void_p(stream)))
+    # check_point_input(targets) happens inside; the batch sizes must agree (core_cuda.cu:566-568)
+    return nfft_forward(targets, yhat, target_batch, m, 1 if real_input else 0)
+
+
+def _coeff_device(device=None):
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return torch.device(device)
+
+
+def gaussian_analytic_coeffs(sigma, N, dim, device=None):
+    """torch_nfft::gaussian_analytic_coeffs(float sigma, int N, int dim) -> Tensor  (core_cuda.cu:855-877)."""
+    device = _coeff_device(device)
+    _assert_input(1 <= dim <= 3 and N >= 2)
+    out = torch.empty((N,) * dim, dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        _lib.check(_lib.load().nfft_hip_gaussian_analytic_coeffs(float(sigma), N, dim, _ptr(out), ctypes.c_void_p(stream)))
+    return out
+
+
+def _coeffs_ws(N, dim, device):
+    nbytes = _lib.load().nfft_hip_coeffs_workspace_bytes(N, dim)
+    if nbytes < 0:
+        _lib.check(_lib.EINVAL if _lib.last_error().startswith("Input mismatch") else _lib.EFFT)
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+def gaussian_interpolated_coeffs(sigma, N, dim, p, eps, device=None):
+    """torch_nfft::gaussian_interpolated_coeffs(float sigma, int N, int dim, int p, float eps) -> Tensor
+    (core_cuda.cu:880-941)."""
+    device = _coeff_device(device)
+    _assert_input(1 <= dim <= 3 and N >= 2)
+    if p > 0:
+        raise RuntimeError("Gaussian interpolated coeffs are currently only implemented for p<=0")
+    if eps != 0.0:
+        raise RuntimeError("Gaussian interpolated coeffs are currently only implemented for eps=0")
+    out = torch.empty((N,) * dim, dtype=torch.complex64, device=device)
+    with torch.cuda.device(device):
+        ws = _coeffs_ws(N, dim, device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        _lib.check(_lib.load().nfft_hip_gaussian_interpolated_coeffs(float(sigma), N, dim, int(p), float(eps), _ptr(out),
+                                                                     _ptr(ws), ws.numel(), ctypes.c_void_p(stream)))
+    return out
+
+
+def interpolation_grid(N, dim, device=None):
+    """torch_nfft::interpolation_grid(int N, int dim) -> Tensor [N]*dim + [dim]  (core_cuda.cu:944-966)."""
+    device = _coeff_device(device)
+    _assert_input(1 <= dim <= 3 and N >= 2)
+    out = torch.empty((N,) * dim + (dim,), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        _lib.check(_lib.load().nfft_hip_interpolation_grid(N, dim, 0, _ptr(out), ctypes.c_void_p(stream)))
+    return out
+
+
+def radial_interpolation_grid(N, dim, device=None):
+    """torch_nfft::radial_interpolation_grid(int N, int dim) -> Tensor [N]*dim  (core_cuda.cu:969-991)."""
+    device = _coeff_device(device)
+    _assert_input(1 <= dim <= 3 and N >= 2)
+    out = torch.empty((N,) * dim, dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        _lib.check(_lib.load().nfft_hip_interpolation_grid(N, dim, 1, _ptr(out), ctypes.c_void_p(stream)))
+    return out
+
+
+def interpolated_kernel_coeffs(grid_values):
+    """torch_nfft::interpolated_kernel_coeffs(Tensor grid_values) -> Tensor  (core_cuda.cu:994-1064)."""
+    if not grid_values.is_cuda:
+        raise RuntimeError("torch_nfft.interpolated_kernel_coeffs is currently only implemented for GPU tensors")
+    dim = grid_values.dim()
+    _assert_input(1 <= dim <= 3)
+    N = grid_values.size(0)
+    for d in range(1, dim):
+        _assert_input(grid_values.size(d) == N)
+    real = _is_real(grid_values)
+    vals = grid_values.contiguous()
+    out = torch.empty((N,) * dim, dtype=torch.complex64, device=vals.device)
+    with torch.cuda.device(vals.device):
+        ws = _coeffs_ws(N, dim, vals.device)
+        stream = torch.cuda.current_stream(vals.device).cuda_stream
+        _lib.check(_lib.load().nfft_hip_interpolated_kernel_coeffs(_ptr(vals), 0 if real else 1, N, dim, _ptr(out),
+                                                                   _ptr(ws), ws.numel(), ctypes.c_void_p(stream)))
+    return out
+
+
 _registered = False
 
 
@@ -195,7 +311,20 @@ def register():
         return
     lib.define("nfft_adjoint(Tensor pos, Tensor x, Tensor? batch, int N, int m, int real_output) -> Tensor")
     lib.define("nfft_forward(Tensor pos, Tensor x, Tensor? batch, int m, int real_output) -> Tensor")
+    lib.define("nfft_fastsum(Tensor sources, Tensor targets, Tensor x, Tensor coeffs, Tensor? source_batch, "
+               "Tensor? target_batch, int m) -> Tensor")
+    lib.define("gaussian_analytic_coeffs(float sigma, int N, int dim) -> Tensor")
+    lib.define("gaussian_interpolated_coeffs(float sigma, int N, int dim, int p, float eps) -> Tensor")
+    lib.define("interpolation_grid(int N, int dim) -> Tensor")
+    lib.define("radial_interpolation_grid(int N, int dim) -> Tensor")
+    lib.define("interpolated_kernel_coeffs(Tensor grid_values) -> Tensor")
     lib.impl("nfft_adjoint", nfft_adjoint, "CompositeExplicitAutograd")
     lib.impl("nfft_forward", nfft_forward, "CompositeExplicitAutograd")
+    lib.impl("nfft_fastsum", nfft_fastsum, "CompositeExplicitAutograd")
+    lib.impl("gaussian_analytic_coeffs", gaussian_analytic_coeffs, "CompositeExplicitAutograd")
+    lib.impl("gaussian_interpolated_coeffs", gaussian_interpolated_coeffs, "CompositeExplicitAutograd")
+    lib.impl("interpolation_grid", interpolation_grid, "CompositeExplicitAutograd")
+    lib.impl("radial_interpolation_grid", radial_interpolation_grid, "CompositeExplicitAutograd")
+    lib.impl("interpolated_kernel_coeffs", interpolated_kernel_coeffs, "CompositeExplicitAutograd")
     register._lib = lib  # keep alive
     _registered = True
