@@ -1,0 +1,126 @@
+"""GPU parity at BASELINE.json's full sizes, through size-independent checks (a dense oracle is impossible:
+the exact NDFT of config C3 is 1.7e14 point-frequency pairs):
+
+  * adjoint: a random subset of frequencies against the chunked float64 NDFT (oracle.ndft.ndft_adjoint_subset);
+  * forward: a spectrum with a handful of non-zero frequencies, for which the exact result is a short sum;
+  * adjointness <A x, y> = <x, A^H y> between the two transforms at full size;
+  * linearity in x;
+  * fastsum (config C5): a subset of targets against the exact Gaussian kernel sums.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import ndft
+
+pytestmark = pytest.mark.gpu
+T2_M4 = 5e-4
+
+
+@pytest.fixture(scope="module")
+def tn():
+    import torch_nfft_amd
+    return torch_nfft_amd
+
+
+def _subset_check_adjoint(tn, d, N, m, n, nfreq, seed):
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    pos = torch.rand((n, d), generator=gen, device="cuda") - 0.5
+    x = torch.rand((n,), generator=gen, device="cuda")
+    y = tn.nfft_adjoint(x, pos, None, bandwidth=N, cutoff=m)
+    rng = np.random.default_rng(seed)
+    freqs = rng.integers(-N // 2, N // 2, size=(nfreq, d))
+    exact = ndft.ndft_adjoint_subset(x.cpu().numpy()[:, None], pos.cpu().numpy(), freqs)[:, 0]
+    got = y[0].cpu().numpy()[tuple((freqs + N // 2).T)]
+    return pos, x, y, rel_l2(got, exact)
+
+
+def _sparse_forward_check(tn, pos, N, m, nnz, seed):
+    d = pos.shape[1]
+    rng = np.random.default_rng(seed)
+    freqs = rng.integers(-N // 2, N // 2, size=(nnz, d))
+    vals = (rng.standard_normal(nnz) + 1j * rng.standard_normal(nnz)).astype(np.complex64)
+    xh = torch.zeros((1,) + (N,) * d, dtype=torch.complex64, device="cuda")
+    for f, v in zip(freqs, vals):
+        xh[(0,) + tuple(f + N // 2)] += complex(v)
+    y = tn.nfft_forward(xh, pos, None, cutoff=m)
+    sel = rng.integers(0, pos.shape[0], size=4096)
+    p = pos[sel].cpu().numpy().astype(np.float64)
+    exact = (np.exp(-2j * np.pi * (p @ freqs.T.astype(np.float64))) * vals[None, :].astype(np.complex128)).sum(1)
+    return xh, y, rel_l2(y[sel].cpu().numpy(), exact)
+
+
+def test_config_c2_2d_n128_m4_100k(tn):
+    pos, x, y, err = _subset_check_adjoint(tn, 2, 128, 4, 100_000, 256, 2)
+    assert y.shape == (1, 128, 128) and err < T2_M4
+    _, yf, errf = _sparse_forward_check(tn, pos, 128, 4, 12, 3)
+    assert errf < T2_M4
+
+
+def test_config_c3_3d_n256_m4_10m(tn):
+    n, N, m = 10_000_000, 256, 4
+    pos, x, y, err = _subset_check_adjoint(tn, 3, N, m, n, 48, 4)
+    assert y.shape == (1, N, N, N) and err < T2_M4
+    xh, yf, errf = _sparse_forward_check(tn, pos, N, m, 8, 5)
+    assert yf.shape == (n,) and errf < T2_M4
+    # adjointness at full size: <A x, xh> = <x, A^H xh>  (A = adjoint transform, A^H = forward transform)
+    lhs = torch.sum(y * xh.conj())
+    rhs = torch.sum(x.to(torch.complex64) * yf.conj())
+    assert abs(complex(lhs) - complex(rhs)) < 1e-4 * abs(complex(lhs)) + 1e-2
+    # linearity
+    x2 = torch.rand_like(x)
+    y2 = tn.nfft_adjoint(x2, pos, None, bandwidth=N, cutoff=m)
+    y12 = tn.nfft_adjoint(x + 2 * x2, pos, None, bandwidth=N, cutoff=m)
+    assert rel_l2((y + 2 * y2).cpu().numpy(), y12.cpu().numpy()) < 2e-6
+
+
+def test_config_c4_shape_batched_columns_chunked(tn, monkeypatch):
+    """Config C4's structure (3-D N=128, m=4, several point sets x several columns) at a size that runs in seconds,
+    with a chunk budget that forces the plane loop: subset of frequencies vs the exact NDFT per (batch, column)."""
+    from torch_nfft_amd import ops
+    N, m, B, C, n_per = 128, 4, 3, 4, 20_000
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    pos = torch.rand((B * n_per, 3), generator=gen, device="cuda") - 0.5
+    batch = torch.arange(B * n_per, device="cuda") // n_per
+    x = torch.randn((B * n_per, C), generator=gen, device="cuda")
+    monkeypatch.setenv("NFFT_HIP_CHUNK_BYTES", str(5 * (256 ** 3 * 4 + 256 * 256 * 129 * 8 + 300_000_000)))
+    ops._ws_bytes_cache.clear()
+    y = tn.nfft_adjoint(x, pos, batch, bandwidth=N, cutoff=m)
+    assert y.shape == (B, N, N, N, C)
+    rng = np.random.default_rng(8)
+    freqs = rng.integers(-N // 2, N // 2, size=(64, 3))
+    for b in range(B):
+        sel = slice(b * n_per, (b + 1) * n_per)
+        exact = ndft.ndft_adjoint_subset(x[sel].cpu().numpy(), pos[sel].cpu().numpy(), freqs)
+        got = y[b].cpu().numpy()[tuple((freqs + N // 2).T)]
+        assert rel_l2(got, exact) < T2_M4
+    z = tn.nfft_forward(y, pos, batch, cutoff=m, real_output=True)
+    assert z.shape == (B * n_per, C)
+    # <A x, A x> = <x, A^H A x>
+    lhs = float((y.abs() ** 2).sum())
+    rhs = float((x * z).sum())
+    assert abs(lhs - rhs) < 1e-4 * lhs
+    ops._ws_bytes_cache.clear()
+
+
+def test_config_c5_fastsum_1m_x_1m(tn):
+    """Gaussian kernel sums, 1e6 sources x 1e6 targets, 3-D N=256, m=4 (test_fastsum.py geometry: points in the
+    ball of radius 1/4): 256 targets against the exact sums."""
+    ns = nt = 1_000_000
+    N, m, sigma = 256, 4, 0.1
+    gen = torch.Generator(device="cuda").manual_seed(11)
+
+    def ball(k):
+        p = torch.rand((k, 3), generator=gen, device="cuda") - 0.5
+        return p * (0.25 / torch.linalg.norm(p, dim=1).max())
+
+    src, tgt = ball(ns), ball(nt)
+    x = torch.rand((ns,), generator=gen, device="cuda")
+    coeffs = tn.gaussian_analytic_coeffs(sigma, dim=3, N=N)
+    y = tn.nfft_fastsum(x, coeffs, src, tgt, cutoff=m)
+    assert y.shape == (nt,) and y.dtype == torch.float32
+    sel = torch.arange(0, nt, nt // 256, device="cuda")[:256]
+    d2 = ((tgt[sel, None, :].double() - src[None, :, :].double()) ** 2).sum(-1)
+    exact = (torch.exp(-d2 / sigma ** 2) * x.double()[None, :]).sum(1)
+    assert rel_l2(y[sel].cpu().numpy(), exact.cpu().numpy()) < 1e-3
