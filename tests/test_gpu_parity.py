@@ -359,6 +359,36 @@ def test_plan_cache_follows_in_place_updates(tn):
     assert rel_l2(host(y3), host(y2)) < 1e-6
 
 
+def test_register_tile_spreading_mode_is_deterministic():
+    """NFFT_HIP_SPREAD=reg (read once per process) selects the atomics-free register-tile spreading kernel:
+    same numbers as the oracle, and bitwise identical results run to run."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+import torch_nfft_amd as tn
+from oracle import nfft_ref
+rng = np.random.default_rng(3)
+n, N, m = 3000, 32, 4
+pos = (rng.random((n, 3)) - 0.5).astype(np.float32)
+pos[:500] = (0.02 * rng.standard_normal((500, 3)) + 0.4999).astype(np.float32)   # cluster on the periodic corner
+batch = np.sort(rng.integers(0, 2, n)).astype(np.int64); batch[0], batch[-1] = 0, 1
+x = rng.standard_normal((n, 2)).astype(np.float32)
+args = [torch.from_numpy(a).cuda() for a in (x, pos, batch)]
+y1 = tn.nfft_adjoint(*args, bandwidth=N, cutoff=m)
+y2 = tn.nfft_adjoint(*args, bandwidth=N, cutoff=m)
+ref = nfft_ref.nfft_adjoint(x, pos, batch, N=N, m=m)
+err = np.linalg.norm(y1.cpu().numpy() - ref) / np.linalg.norm(ref)
+print("RESULT", err, bool(torch.equal(y1, y2)))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NFFT_HIP_SPREAD="reg")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    assert float(line[1]) < T1 and line[2] == "True"
+
+
 def test_clustered_points_many_per_tile(tn):
     """All points inside one grid cell neighbourhood: stresses LDS accumulation order and the chunk sweep."""
     rng = np.random.default_rng(71)

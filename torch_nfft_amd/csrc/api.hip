@@ -49,6 +49,15 @@ StageTimer::~StageTimer()
     if (slot >= 0) (void)hipEventRecord(g_spans[slot].stop, stream);
 }
 
+bool subblock_plan_enabled()
+{
+    static const bool on = [] {
+        const char *env = std::getenv("NFFT_HIP_SPREAD");
+        return env && env[0] == 'r';
+    }();
+    return on;
+}
+
 namespace {
 
 int validate(const nfft_hip_problem *p)
@@ -87,6 +96,20 @@ struct Carve {
     bool colfft;  // pruned column passes (colfft.hip) instead of the full dim-dimensional rocFFT transform
     int64_t off_plan, off_xs, off_grid, off_spec, off_col, off_work, work_bytes, total;
 };
+
+bool spread_reg_enabled() { return subblock_plan_enabled(); }
+
+int spread_any(const Geom &g, const PlanLayout &L, const void *plan, const float *xs, int64_t n, int64_t Cr,
+               int64_t p0, int64_t np, float *grid, hipStream_t s)
+{
+    if (spread_reg_supported(g) && spread_reg_enabled()) {
+        StageTimer t(kStageSpread, s);
+        return launch_spread_reg(g, L, plan, xs, n, Cr, p0, np, grid, s);
+    }
+    { StageTimer t(kStageZero, s); NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(np * g.cells * 4), s)); }
+    StageTimer t(kStageSpread, s);
+    return launch_spread(g, L, plan, xs, n, Cr, p0, np, grid, s);
+}
 
 bool colfft_enabled()
 {
@@ -216,8 +239,7 @@ int nfft_hip_spread(const nfft_hip_problem *p, const void *plan, const float *xr
     const int64_t planes = p->batch_size * real_columns;
     if (planes > 32768) { set_error("Input mismatch: too many planes for one spread call"); return NFFT_HIP_EINVAL; }
     if (int rc = launch_gather_rows(g, L, plan, p->num_points, xr, real_columns, scratch, s)) return rc;
-    NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(planes * g.cells * 4), s));
-    return launch_spread(g, L, plan, scratch, p->num_points, real_columns, 0, planes, grid, s);
+    return spread_any(g, L, plan, scratch, p->num_points, real_columns, 0, planes, grid, s);
 }
 
 int nfft_hip_interpolate(const nfft_hip_problem *p, const void *plan, const float *grid, int64_t real_columns,
@@ -259,8 +281,7 @@ static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64
     { StageTimer t(kStageGather, s); if (int rc = launch_gather_rows(c.g, c.L, plan, c.n, (const float *)x, c.Cr, xs, s)) return rc; }
     for (int64_t p0 = 0; p0 < c.total_planes; p0 += c.chunk_planes) {
         const int64_t np = std::min(c.chunk_planes, c.total_planes - p0);
-        { StageTimer t(kStageZero, s); NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(np * c.g.cells * 4), s)); }
-        { StageTimer t(kStageSpread, s); if (int rc = launch_spread(c.g, c.L, plan, xs, c.n, c.Cr, p0, np, grid, s)) return rc; }
+        if (int rc = spread_any(c.g, c.L, plan, xs, c.n, c.Cr, p0, np, grid, s)) return rc;
         if (c.colfft) {
             { StageTimer t(kStageFft, s); if (int rc = fft_execute(kR2CRows, c.g.dim, c.g.M, np, grid, spec, work, c.work_bytes, s)) return rc; }
             { StageTimer t(kStageDeconv, s); if (int rc = launch_colfft_adjoint(c.g, spec, ws + c.off_col, c.chunk_planes, c.C, x_is_complex, real_output, p0, np, y, s)) return rc; }

@@ -18,7 +18,7 @@ constexpr int kMaxPencilsLds = 8192;    // first-level bins that fit an LDS hist
 PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)
 {
     PlanLayout L;
-    L.ntiles = (int64_t)g.tiles_per_batch * B;
+    L.ntiles = (int64_t)g.tiles_per_batch * B * g.SB;  // (tile, sub-block) bins
     L.npencils = (int64_t)g.nta[1] * g.nta[2] * B;
     L.nblocks = (n + kSortBlockPoints - 1) / kSortBlockPoints;
     L.two_level = L.npencils <= kMaxPencilsLds && L.npencils * L.nblocks < (int64_t(1) << 28) && n > 0;
@@ -49,7 +49,7 @@ __device__ __forceinline__ int point_tile(const Geom &g, const float *__restrict
     }
     int64_t b = batch ? batch[i] : 0;
     b = b < 0 ? 0 : (b >= B ? B - 1 : b);
-    return (int)b * g.tiles_per_batch + tile_of_cells(g, cell);
+    return ((int)b * g.tiles_per_batch + tile_of_cells(g, cell)) * g.SB + sub_of_cells(g, cell);
 }
 
 __global__ void __launch_bounds__(256) bin_count_kernel(Geom g, const float *__restrict__ pos,
@@ -138,24 +138,35 @@ sort1_scatter_kernel(Geom g, const float *__restrict__ pos, const int64_t *__res
     }
 }
 
+// (chunk, sub-block) key of a level-1 record inside its pencil
+__device__ __forceinline__ int fine_key(const Geom &g, const float4 rec)
+{
+    if (g.dim != 3) return 0;
+    int cell[3];
+    float fr;
+    split_cell(rec.x, g.M, cell[0], fr);
+    int key = cell[0] / g.Ta[0];
+    if (g.SB > 1) {
+        split_cell(rec.y, g.M, cell[1], fr);
+        split_cell(rec.z, g.M, cell[2], fr);
+        key = key * g.SB + sub_of_cells(g, cell);
+    }
+    return key;
+}
+
 __global__ void __launch_bounds__(kSortThreads)
 sort2_kernel(Geom g, int64_t n, int npencils, int nblocks, const int *__restrict__ hscan,
              const float4 *__restrict__ tmp, int *__restrict__ offsets, int *__restrict__ perm,
              float *__restrict__ spos)
 {
-    extern __shared__ int lds2[];  // [nt0] counts -> cursors, + scan scratch
+    extern __shared__ int lds2[];  // [nt0 * SB] counts -> cursors
     const int pencil = blockIdx.x;
-    const int nt0 = g.nta[0];
+    const int nt0 = g.nta[0] * g.SB;  // (chunk, sub-block) bins of this pencil
     const int p0 = hscan[(int64_t)pencil * nblocks];
     const int p1 = pencil + 1 < npencils ? hscan[(int64_t)(pencil + 1) * nblocks] : (int)n;
     for (int i = threadIdx.x; i < nt0; i += kSortThreads) lds2[i] = 0;
     __syncthreads();
-    for (int j = p0 + threadIdx.x; j < p1; j += kSortThreads) {
-        int c0 = 0;
-        float fr;
-        if (g.dim == 3) split_cell(tmp[j].x, g.M, c0, fr);
-        atomicAdd(&lds2[c0 / g.Ta[0]], 1);
-    }
+    for (int j = p0 + threadIdx.x; j < p1; j += kSortThreads) atomicAdd(&lds2[fine_key(g, tmp[j])], 1);
     __syncthreads();
     // exclusive scan of the nt0 chunk counts by one wave (nt0 is small: M / TC)
     if (threadIdx.x < 64) {
@@ -180,10 +191,7 @@ sort2_kernel(Geom g, int64_t n, int npencils, int nblocks, const int *__restrict
     __syncthreads();
     for (int j = p0 + threadIdx.x; j < p1; j += kSortThreads) {
         const float4 rec = tmp[j];
-        int c0 = 0;
-        float fr;
-        if (g.dim == 3) split_cell(rec.x, g.M, c0, fr);
-        const int slot = p0 + atomicAdd(&lds2[c0 / g.Ta[0]], 1);
+        const int slot = p0 + atomicAdd(&lds2[fine_key(g, rec)], 1);
         perm[slot] = __float_as_int(rec.w);
         spos[(int64_t)slot * g.dim] = rec.x;
         if (g.dim > 1) spos[(int64_t)slot * g.dim + 1] = rec.y;
@@ -233,7 +241,7 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
         NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(base + L.off_scan, scan_bytes, hist, hscan, (int)items, stream));
         hipLaunchKernelGGL(sort1_scatter_kernel, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
                            npencils, nblocks, hscan, tmp);
-        hipLaunchKernelGGL(sort2_kernel, dim3(npencils), dim3(kSortThreads), (size_t)g.nta[0] * 4, stream, g, n,
+        hipLaunchKernelGGL(sort2_kernel, dim3(npencils), dim3(kSortThreads), (size_t)g.nta[0] * g.SB * 4, stream, g, n,
                            npencils, nblocks, hscan, tmp, offsets, perm, spos);
         NFFT_HIP_CHECK(hipGetLastError());
         return 0;

@@ -42,8 +42,13 @@ constexpr TileCfg tile_cfg(int dim, int W)
                     : TileCfg{1, 256, 1, 1};
 }
 constexpr int kSegChunks = 8;   // chunks swept by one workgroup
+constexpr int kSub = 8;         // edge of a sub-block (cells): one wave of the register-tile spreading kernel owns kSub x kSub cells
 constexpr int kMaxW = 18;       // 2m+2 for m <= 8
 constexpr int kMaxCutoff = 8;
+
+// NFFT_HIP_SPREAD=reg (read once per process) selects the atomics-free, bitwise reproducible register-tile
+// spreading kernel (spread_reg.hip) and the finer point-plan order it needs.
+bool subblock_plan_enabled();
 
 struct Geom {
     int dim;      // user dimension 1..3
@@ -56,7 +61,11 @@ struct Geom {
     int Ta[3];    // tile extent per internal axis (Ta[0] = planes per chunk)
     int nta[3];   // tiles per internal axis
     int nseg;     // segments per pencil
-    int tiles_per_batch;
+    int tiles_per_batch;  // (pencil, chunk) tiles per point set
+    // Every tile is further split into sb1 x sb2 sub-blocks of kSub x kSub cells in (axis 1, axis 2); the point
+    // plan is sorted down to (tile, sub-block), so a tile's points are contiguous AND grouped by sub-block.
+    // tile_offsets has one entry per (tile, sub-block): index tile * SB + s1 * sb2 + s2.
+    int sb1, sb2, SB;
     int64_t cells; // M^dim
 };
 
@@ -85,6 +94,12 @@ inline Geom make_geom(int dim, int64_t N, int64_t m)
     }
     g.nseg = (g.nta[0] + kSegChunks - 1) / kSegChunks;
     g.tiles_per_batch = g.nta[0] * g.nta[1] * g.nta[2];
+    // only the opt-in register-tile spreading kernel needs the sub-block order (it costs ~0.25 ms of sorting at C3)
+    const bool sub = subblock_plan_enabled() && dim == 3 && g.M % kSub == 0 && g.Ta[1] % kSub == 0 &&
+                     g.Ta[2] % kSub == 0;
+    g.sb1 = sub ? g.Ta[1] / kSub : 1;
+    g.sb2 = sub ? g.Ta[2] / kSub : 1;
+    g.SB = g.sb1 * g.sb2;
     return g;
 }
 
@@ -149,10 +164,19 @@ __device__ __forceinline__ int tile_of_cells(const Geom &g, const int cell[3])
     return (j1 * g.nta[2] + j2) * g.nta[0] + k0;
 }
 
+// Sub-block of a point inside its tile: s1 * sb2 + s2 (0 when the tile is not subdivided).
+__device__ __forceinline__ int sub_of_cells(const Geom &g, const int cell[3])
+{
+    if (g.SB == 1) return 0;
+    const int s1 = (cell[1] % g.Ta[1]) / kSub;
+    const int s2 = (cell[2] % g.Ta[2]) / kSub;
+    return s1 * g.sb2 + s2;
+}
+
 #endif // __HIPCC__
 
 // ---- plan layout -----------------------------------------------------------
-// [ tile_offset int32[ntiles+1] | cursor int32[ntiles] | perm int32[n] | spos float[n*dim] | scan temp | sort scratch ]
+// [ tile_offset int32[ntiles*SB+1] | cursor int32[ntiles] | perm int32[n] | spos float[n*dim] | scan temp | sort scratch ]
 struct PlanLayout {
     int64_t ntiles;
     int64_t npencils, nblocks;  // two-level sort geometry

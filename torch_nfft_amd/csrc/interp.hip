@@ -70,7 +70,7 @@ interp_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__r
     const int k_begin = seg * kSegChunks;
     const int k_end = min(g.nta[0], k_begin + kSegChunks);
     const int tile0 = b * g.tiles_per_batch + pencil * g.nta[0];
-    if (tile_offsets[tile0 + k_begin] == tile_offsets[tile0 + k_end]) return;
+    if (tile_offsets[(tile0 + k_begin) * g.SB] == tile_offsets[(tile0 + k_end) * g.SB]) return;
 
     const int m = g.m;
     const int tb1 = j1 * g.Ta[1], tb2 = j2 * g.Ta[2];
@@ -83,7 +83,7 @@ interp_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__r
     int base_z = 0, have = 0;
 
     for (int k = k_begin; k < k_end; ++k) {
-        const int s = tile_offsets[tile0 + k], e = tile_offsets[tile0 + k + 1];
+        const int s = tile_offsets[(tile0 + k) * g.SB], e = tile_offsets[(tile0 + k + 1) * g.SB];
         if (e == s) continue;
         const int want_z = k * C::TC - C::M0OFF;
         // slide the planes that are still needed down (linear LDS move in batches of `shift` planes: batch b

@@ -15,6 +15,12 @@ int launch_gather_rows(const Geom &g, const PlanLayout &L, const void *plan, int
 int launch_spread(const Geom &g, const PlanLayout &L, const void *plan, const float *xs, int64_t n, int64_t Cr,
                   int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream);
 
+// spread_reg.hip: register-tile spreading for 3-D grids (no atomics; writes every cell of the planes, so the
+// grid needs no zero-fill).  Same arguments as launch_spread.
+bool spread_reg_supported(const Geom &g);
+int launch_spread_reg(const Geom &g, const PlanLayout &L, const void *plan, const float *xs, int64_t n, int64_t Cr,
+                      int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream);
+
 // interp.hip: yr[perm[slot] * Cr + cr] = sum over taps of grid[p, ...]
 int launch_interp(const Geom &g, const PlanLayout &L, const void *plan, const float *grid, int64_t n, int64_t Cr,
                   int64_t plane0, int64_t nplanes, float *yr, hipStream_t stream);
