@@ -42,6 +42,20 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(d, N, m, n):
+    """HBM bytes per launch of the spreading kernel from the committed rocprofv3 PMC passes (FETCH_SIZE with the
+    gfx950 x2 correction + WRITE_SIZE; profiles/r01_v2_spread_traffic.json), if they were taken on this workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_v2_spread_traffic.json")) as f:
+            t = json.load(f)
+        w = t["workload"]
+        if (w["dim"], w["bandwidth"], w["cutoff"], w["points"]) == (d, N, m, n):
+            return t["fetch_bytes_corrected"] + t["write_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(dim, N, target_s):
     """Oracle (this repo's restatement of torch_nfft/ndft.py, plain C + OpenMP) timed on the host cores on a
     bounded sample of the same workload: all N^dim frequencies, n' points (cost is linear in n')."""
@@ -172,7 +186,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(d, N, m, n),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": sp_avg,
                 "launches": sp_cnt,
