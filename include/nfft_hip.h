@@ -106,7 +106,7 @@ int nfft_hip_plan_points(const nfft_hip_problem *p, const float *pos, const int6
  * over real columns cr (a complex x is viewed as 2C real columns).  Replaces
  * real_/complex_adjoint_window_convolution_kernel (spatial_window_operations.cu:103-211).
  *   grid  float32 [B*Cr, (2N)^dim] real planes; zero-filled by this call.
- *   scratch  float32 [n * Cr] for the tile-ordered copy of xr. */
+ *   scratch  float32 [roundup(n * Cr, 64) + 64]: the tile-ordered copy of xr and its maximum magnitude. */
 int nfft_hip_spread(const nfft_hip_problem *p, const void *plan, const float *xr, int64_t real_columns,
                     float *grid, float *scratch, void *stream);
 

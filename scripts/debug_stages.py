@@ -25,7 +25,7 @@ def run(d, N, m, n, B, Cr, seed=0):
     _lib.check(lib.nfft_hip_plan_points(ctypes.byref(prob), p(post), p(bt), p(plan), plan.numel(), s))
     M = 2*N
     grid = torch.full((B*Cr,)+(M,)*d, float('nan'), device='cuda')
-    scratch = torch.empty(n*Cr, device='cuda')
+    scratch = torch.empty(n*Cr + 128, device='cuda')
     _lib.check(lib.nfft_hip_spread(ctypes.byref(prob), p(plan), p(xt), Cr, p(grid), p(scratch), s))
     torch.cuda.synchronize()
     ref = nfft_ref.spread(x, pos, batch, N, m).real.reshape((B*Cr,)+(M,)*d)

@@ -14,7 +14,7 @@ plan = torch.empty(lib.nfft_hip_plan_bytes(ctypes.byref(prob)), dtype=torch.uint
 s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 _lib.check(lib.nfft_hip_plan_points(ctypes.byref(prob), p(pos), None, p(plan), plan.numel(), s))
 grid = torch.empty((2 * N,) * 3, device="cuda")
-scratch = torch.empty(n, device="cuda")
+scratch = torch.empty(n + 128, device="cuda")
 for mode in [int(v) for v in os.environ.get("MODES", "0,1,2,3,6,9").split(",")]:
     os.environ["NFFT_HIP_DBG"] = str(mode)
     for it in range(3):

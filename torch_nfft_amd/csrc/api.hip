@@ -49,13 +49,15 @@ StageTimer::~StageTimer()
     if (slot >= 0) (void)hipEventRecord(g_spans[slot].stop, stream);
 }
 
-bool subblock_plan_enabled()
+SpreadMode spread_mode()
 {
-    static const bool on = [] {
+    static const SpreadMode mode = [] {
         const char *env = std::getenv("NFFT_HIP_SPREAD");
-        return env && env[0] == 'r';
+        if (env && env[0] == 'r') return kSpreadReg;
+        if (env && env[0] == 'm') return kSpreadMfma;
+        return kSpreadLds;
     }();
-    return on;
+    return mode;
 }
 
 namespace {
@@ -99,9 +101,17 @@ struct Carve {
 
 bool spread_reg_enabled() { return subblock_plan_enabled(); }
 
+// xs holds Cr * n gathered coefficients followed (64-float aligned) by max |x|
+inline const float *maxabs_of(const float *xs, int64_t n, int64_t Cr) { return xs + align_up(n * Cr, 64); }
+
 int spread_any(const Geom &g, const PlanLayout &L, const void *plan, const float *xs, int64_t n, int64_t Cr,
                int64_t p0, int64_t np, float *grid, hipStream_t s)
 {
+    if (spread_mfma_supported(g)) {
+        { StageTimer t(kStageZero, s); NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(np * g.cells * 4), s)); }
+        StageTimer t(kStageSpread, s);
+        return launch_spread_mfma(g, L, plan, xs, maxabs_of(xs, n, Cr), n, Cr, p0, np, grid, s);
+    }
     if (spread_reg_supported(g) && spread_reg_enabled()) {
         StageTimer t(kStageSpread, s);
         return launch_spread_reg(g, L, plan, xs, n, Cr, p0, np, grid, s);
@@ -153,7 +163,7 @@ int make_carve(const nfft_hip_problem *p, int planes_per_col, bool need_xs, FftK
     }
     int64_t o = 0;
     c.off_plan = o; o = align_up(o + c.L.total, 256);
-    c.off_xs = o;   o = align_up(o + (need_xs ? c.n * c.Cr * 4 : 0), 256);
+    c.off_xs = o;   o = align_up(o + (need_xs ? (align_up(c.n * c.Cr, 64) + 64) * 4 : 0), 256);
     c.off_grid = o; o = align_up(o + chunk * c.g.cells * 4, 256);
     c.off_spec = o; o = align_up(o + chunk * c.half_cells * 8, 256);
     c.off_col = o;  o = align_up(o + (c.colfft ? colfft_scratch_bytes(c.g, chunk) : 0), 256);
@@ -238,7 +248,7 @@ int nfft_hip_spread(const nfft_hip_problem *p, const void *plan, const float *xr
     hipStream_t s = (hipStream_t)stream;
     const int64_t planes = p->batch_size * real_columns;
     if (planes > 32768) { set_error("Input mismatch: too many planes for one spread call"); return NFFT_HIP_EINVAL; }
-    if (int rc = launch_gather_rows(g, L, plan, p->num_points, xr, real_columns, scratch, s)) return rc;
+    if (int rc = launch_gather_rows(g, L, plan, p->num_points, xr, real_columns, scratch, g.wide ? scratch + align_up(p->num_points * real_columns, 64) : nullptr, s)) return rc;
     return spread_any(g, L, plan, scratch, p->num_points, real_columns, 0, planes, grid, s);
 }
 
@@ -278,7 +288,7 @@ static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64
         if (int rc = launch_plan_points(c.g, c.L, pos, batch, c.n, c.B, ws + c.off_plan, s)) return rc;
         plan = ws + c.off_plan;
     }
-    { StageTimer t(kStageGather, s); if (int rc = launch_gather_rows(c.g, c.L, plan, c.n, (const float *)x, c.Cr, xs, s)) return rc; }
+    { StageTimer t(kStageGather, s); if (int rc = launch_gather_rows(c.g, c.L, plan, c.n, (const float *)x, c.Cr, xs, c.g.wide ? xs + align_up(c.n * c.Cr, 64) : nullptr, s)) return rc; }
     for (int64_t p0 = 0; p0 < c.total_planes; p0 += c.chunk_planes) {
         const int64_t np = std::min(c.chunk_planes, c.total_planes - p0);
         if (int rc = spread_any(c.g, c.L, plan, xs, c.n, c.Cr, p0, np, grid, s)) return rc;

@@ -145,7 +145,7 @@ __device__ __forceinline__ int fine_key(const Geom &g, const float4 rec)
     int cell[3];
     float fr;
     split_cell(rec.x, g.M, cell[0], fr);
-    int key = cell[0] / g.Ta[0];
+    int key = cell[0] / g.bin0;
     if (g.SB > 1) {
         split_cell(rec.y, g.M, cell[1], fr);
         split_cell(rec.z, g.M, cell[2], fr);
@@ -161,7 +161,7 @@ sort2_kernel(Geom g, int64_t n, int npencils, int nblocks, const int *__restrict
 {
     extern __shared__ int lds2[];  // [nt0 * SB] counts -> cursors
     const int pencil = blockIdx.x;
-    const int nt0 = g.nta[0] * g.SB;  // (chunk, sub-block) bins of this pencil
+    const int nt0 = g.np0 * g.SB;  // (axis-0 bin, sub-block) bins of this pencil
     const int p0 = hscan[(int64_t)pencil * nblocks];
     const int p1 = pencil + 1 < npencils ? hscan[(int64_t)(pencil + 1) * nblocks] : (int)n;
     for (int i = threadIdx.x; i < nt0; i += kSortThreads) lds2[i] = 0;
@@ -201,12 +201,28 @@ sort2_kernel(Geom g, int64_t n, int npencils, int nblocks, const int *__restrict
 
 // xs[c, slot] = xr[perm[slot], c]  (tile-ordered, column-major copy of the real coefficient columns)
 __global__ void __launch_bounds__(256) gather_rows_kernel(const int *__restrict__ perm, const float *__restrict__ xr,
-                                                         float *__restrict__ xs, int64_t n, int64_t cols)
+                                                         float *__restrict__ xs, int64_t n, int64_t cols,
+                                                         unsigned *__restrict__ maxabs_bits)
 {
     const int64_t total = n * cols;
+    float mx = 0.0f;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t slot = e / cols, c = e - slot * cols;
-        xs[c * n + slot] = xr[(int64_t)perm[slot] * cols + c];
+        const float v = xr[(int64_t)perm[slot] * cols + c];
+        xs[c * n + slot] = v;
+        mx = fmaxf(mx, fabsf(v));
+    }
+    if (maxabs_bits) {
+        // one atomic per workgroup; non-negative floats order like their bit patterns (NaN / inf inputs saturate the
+        // scale, which the consumer clamps)
+        __shared__ float wmax[4];
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            if (mx > 0.0f) atomicMax(maxabs_bits, __float_as_uint(mx));
+        }
     }
 }
 
@@ -241,7 +257,7 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
         NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(base + L.off_scan, scan_bytes, hist, hscan, (int)items, stream));
         hipLaunchKernelGGL(sort1_scatter_kernel, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
                            npencils, nblocks, hscan, tmp);
-        hipLaunchKernelGGL(sort2_kernel, dim3(npencils), dim3(kSortThreads), (size_t)g.nta[0] * g.SB * 4, stream, g, n,
+        hipLaunchKernelGGL(sort2_kernel, dim3(npencils), dim3(kSortThreads), (size_t)g.np0 * g.SB * 4, stream, g, n,
                            npencils, nblocks, hscan, tmp, offsets, perm, spos);
         NFFT_HIP_CHECK(hipGetLastError());
         return 0;
@@ -266,11 +282,13 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
 }
 
 int launch_gather_rows(const Geom &g, const PlanLayout &L, const void *plan, int64_t n, const float *xr, int64_t cols,
-                       float *xs, hipStream_t stream)
+                       float *xs, float *maxabs, hipStream_t stream)
 {
     const int *perm = (const int *)((const char *)plan + L.off_perm);
+    if (maxabs) NFFT_HIP_CHECK(hipMemsetAsync(maxabs, 0, 4, stream));
     if (n * cols > 0)
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n * cols, 256)), dim3(256), 0, stream, perm, xr, xs, n, cols);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n * cols, 256)), dim3(256), 0, stream, perm, xr, xs, n, cols,
+                           (unsigned *)maxabs);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -28,14 +28,17 @@ void set_error(const std::string &msg);
 // segment of SEG chunks of one pencil.
 struct TileCfg {
     int T1, T2; // pencil cross-section (axis 1, axis 2)
-    int NP;     // planes resident in LDS while a chunk is processed
+    int NP;     // planes resident (LDS or registers) while a chunk is processed
     int TC;     // planes per chunk along axis 0: NP - (W - 1), so a chunk's taps fit the resident planes
 };
-// The spreading kernel accumulates in 8-byte cells (ds_add_f64: the 4-byte float LDS atomic is ~45x
-// slower on gfx950, see scripts/ubench/lds_ops.hip), which sets the LDS budget: NP * (T1+W-1) * (T2+W) * 8 B.
-constexpr TileCfg tile_cfg(int dim, int W)
+// Narrow tiling (LDS spreading kernel): it accumulates in 8-byte cells (ds_add_f64: the 4-byte float LDS atomic is
+// ~45x slower on gfx950, scripts/ubench/lds_ops.hip), which sets the budget NP * (T1+W-1) * (T2+W) * 8 B.
+// Wide tiling (MFMA spreading kernel, 3-D): the padded pencil is exactly one 32 x 64 accumulator tile pair,
+// T1 + W - 1 = 32 rows and T2 + W - 1 = 64 columns, and the plan is sorted by single planes ("slabs").
+constexpr TileCfg tile_cfg(int dim, int W, bool wide = false)
 {
-    return dim == 3 ? (W <= 12 ? TileCfg{16, 32, 16, 16 - (W - 1)}
+    return dim == 3 ? (wide ? TileCfg{33 - W, 65 - W, (W <= 16 ? 17 - W : 1) + W - 1, W <= 16 ? 17 - W : 1}
+                     : W <= 12 ? TileCfg{16, 32, 16, 16 - (W - 1)}
                      : W <= 14 ? TileCfg{8, 32, 16, 16 - (W - 1)}
                                : TileCfg{8, 16, 20, 20 - (W - 1)})
          : dim == 2 ? TileCfg{32, 32, 1, 1}
@@ -46,9 +49,14 @@ constexpr int kSub = 8;         // edge of a sub-block (cells): one wave of the 
 constexpr int kMaxW = 18;       // 2m+2 for m <= 8
 constexpr int kMaxCutoff = 8;
 
-// NFFT_HIP_SPREAD=reg (read once per process) selects the atomics-free, bitwise reproducible register-tile
-// spreading kernel (spread_reg.hip) and the finer point-plan order it needs.
-bool subblock_plan_enabled();
+// Spreading kernel for 3-D problems, chosen once per process by NFFT_HIP_SPREAD:
+//   lds  (spread.hip)       ds_add_f64 into LDS-resident planes
+//   mfma (spread_mfma.hip)  per-plane outer products on the matrix cores, accumulators in registers
+//   reg  (spread_reg.hip)   atomics-free register tiles, bitwise reproducible
+// The choice fixes the pencil tiling and the order of the point plan, so it cannot change between calls.
+enum SpreadMode { kSpreadLds = 0, kSpreadMfma = 1, kSpreadReg = 2 };
+SpreadMode spread_mode();
+inline bool subblock_plan_enabled() { return spread_mode() == kSpreadReg; }
 
 struct Geom {
     int dim;      // user dimension 1..3
@@ -59,9 +67,12 @@ struct Geom {
     int Ma[3];    // extent per internal axis (1 when degenerate)
     int Wa[3];    // taps per internal axis (1 when degenerate)
     int Ta[3];    // tile extent per internal axis (Ta[0] = planes per chunk)
-    int nta[3];   // tiles per internal axis
+    int nta[3];   // tiles per internal axis (nta[0] = chunks)
     int nseg;     // segments per pencil
-    int tiles_per_batch;  // (pencil, chunk) tiles per point set
+    int wide;     // wide (MFMA) tiling; the plan then has one bin per plane along axis 0
+    int bin0;     // planes per plan bin along axis 0: Ta[0], or 1 for the wide tiling
+    int np0;      // plan bins per pencil along axis 0
+    int tiles_per_batch;  // plan bins per point set: np0 * nta[1] * nta[2]
     // Every tile is further split into sb1 x sb2 sub-blocks of kSub x kSub cells in (axis 1, axis 2); the point
     // plan is sorted down to (tile, sub-block), so a tile's points are contiguous AND grouped by sub-block.
     // tile_offsets has one entry per (tile, sub-block): index tile * SB + s1 * sb2 + s2.
@@ -84,7 +95,9 @@ inline Geom make_geom(int dim, int64_t N, int64_t m)
         g.Wa[a] = live ? g.W : 1;
         if (live) g.cells *= g.M;
     }
-    const TileCfg tc = tile_cfg(dim, g.W);
+    // 16 waves hold 16 resident planes: the axis-0 window (2m+2 planes) has to fit
+    g.wide = dim == 3 && spread_mode() == kSpreadMfma && g.M >= 64 && g.W <= 16;
+    const TileCfg tc = tile_cfg(dim, g.W, g.wide != 0);
     g.Ta[0] = tc.TC;
     g.Ta[1] = tc.T1;
     g.Ta[2] = tc.T2;
@@ -93,7 +106,9 @@ inline Geom make_geom(int dim, int64_t N, int64_t m)
         g.nta[a] = (g.Ma[a] + g.Ta[a] - 1) / g.Ta[a];
     }
     g.nseg = (g.nta[0] + kSegChunks - 1) / kSegChunks;
-    g.tiles_per_batch = g.nta[0] * g.nta[1] * g.nta[2];
+    g.bin0 = g.wide ? 1 : g.Ta[0];
+    g.np0 = g.wide ? g.Ma[0] : g.nta[0];
+    g.tiles_per_batch = g.np0 * g.nta[1] * g.nta[2];
     // only the opt-in register-tile spreading kernel needs the sub-block order (it costs ~0.25 ms of sorting at C3)
     const bool sub = subblock_plan_enabled() && dim == 3 && g.M % kSub == 0 && g.Ta[1] % kSub == 0 &&
                      g.Ta[2] % kSub == 0;
@@ -155,13 +170,24 @@ __device__ __forceinline__ int wrap_near(int v, int M)
     return v;
 }
 
-// Tile index of a point inside its batch: ((j1 * nt2 + j2) * nt0 + k0); chunks of one pencil are contiguous.
+// Plan bin of a point inside its batch: ((j1 * nt2 + j2) * np0 + k0); the bins of one pencil are contiguous.
 __device__ __forceinline__ int tile_of_cells(const Geom &g, const int cell[3])
 {
-    const int k0 = cell[0] / g.Ta[0];
+    const int k0 = cell[0] / g.bin0;
     const int j1 = cell[1] / g.Ta[1];
     const int j2 = cell[2] / g.Ta[2];
-    return (j1 * g.nta[2] + j2) * g.nta[0] + k0;
+    return (j1 * g.nta[2] + j2) * g.np0 + k0;
+}
+
+// Point range of chunk k (Ta[0] planes) of a pencil: [s, e).  first_bin = index of the pencil's first plan bin.
+__device__ __forceinline__ void chunk_range(const Geom &g, const int *__restrict__ tile_offsets, int first_bin, int k,
+                                            int &s, int &e)
+{
+    const int r = g.Ta[0] / g.bin0;  // plan bins per chunk
+    const int lo = k * r;
+    const int hi = min(lo + r, g.np0);
+    s = tile_offsets[(first_bin + lo) * g.SB];
+    e = tile_offsets[(first_bin + hi) * g.SB];
 }
 
 // Sub-block of a point inside its tile: s1 * sb2 + s2 (0 when the tile is not subdivided).

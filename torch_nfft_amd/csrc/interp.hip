@@ -26,9 +26,9 @@ namespace nfft {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int DIM, int W>
+template <int DIM, int W, bool WIDE>
 struct GatherCfg {
-    static constexpr TileCfg tc = tile_cfg(DIM, W);
+    static constexpr TileCfg tc = tile_cfg(DIM, W, WIDE);
     static constexpr int T1 = tc.T1, T2 = tc.T2, TC = tc.TC;
     static constexpr int W0 = DIM == 3 ? W : 1;
     static constexpr int W1 = DIM >= 2 ? W : 1;
@@ -40,18 +40,18 @@ struct GatherCfg {
     static constexpr int S2 = (P2 + 3 + 3) / 4 * 4;       // row stride (floats): room for the aligned over-read
     static constexpr int S0 = P1 * S2;
     static constexpr int CELLS = NP * S0;
-    static constexpr int NT = DIM == 3 ? 512 : 256;
+    static constexpr int NT = DIM == 3 ? (WIDE ? 1024 : 512) : 256;  // the wide tiling fills the LDS with one workgroup
     static constexpr int NWAVES = NT / 64;
     static_assert(CELLS * 4 <= 160 * 1024, "LDS budget");
 };
 
-template <int DIM, int W>
-__global__ void __launch_bounds__((GatherCfg<DIM, W>::NT))
+template <int DIM, int W, bool WIDE>
+__global__ void __launch_bounds__((GatherCfg<DIM, W, WIDE>::NT))
 interp_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__restrict__ perm,
               const float *__restrict__ spos, const float *__restrict__ grid, const int Cr, const int plane0,
               float *__restrict__ yr)
 {
-    using C = GatherCfg<DIM, W>;
+    using C = GatherCfg<DIM, W, WIDE>;
     constexpr int NT = C::NT;
     constexpr int NWAVES = C::NWAVES;
     __shared__ float4 planes4[C::CELLS / 4];
@@ -72,8 +72,13 @@ interp_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__r
 
     const int k_begin = seg * kSegChunks;
     const int k_end = min(g.nta[0], k_begin + kSegChunks);
-    const int tile0 = b * g.tiles_per_batch + pencil * g.nta[0];
-    if (tile_offsets[(tile0 + k_begin) * g.SB] == tile_offsets[(tile0 + k_end) * g.SB]) return;
+    const int bin0 = b * g.tiles_per_batch + pencil * g.np0;  // first plan bin of this pencil
+    {
+        int s0, e0, s1, e1;
+        chunk_range(g, tile_offsets, bin0, k_begin, s0, e0);
+        chunk_range(g, tile_offsets, bin0, k_end - 1, s1, e1);
+        if (s0 == e1) return;  // no points in this segment
+    }
 
     const int m = g.m;
     const int tb1 = j1 * g.Ta[1], tb2 = j2 * g.Ta[2];
@@ -86,7 +91,8 @@ interp_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__r
     int base_z = 0, have = 0;
 
     for (int k = k_begin; k < k_end; ++k) {
-        const int s = tile_offsets[(tile0 + k) * g.SB], e = tile_offsets[(tile0 + k + 1) * g.SB];
+        int s, e;
+        chunk_range(g, tile_offsets, bin0, k, s, e);
         if (e == s) continue;
         const int want_z = k * C::TC - C::M0OFF;
         // slide the planes that are still needed down (linear LDS move in batches of `shift` planes: batch b
@@ -203,8 +209,16 @@ static int launch_interp_t(const Geom &g, const int *to, const int *perm, const 
                            int64_t Cr, int64_t plane0, int64_t nplanes, float *yr, hipStream_t stream)
 {
     const dim3 blocks((unsigned)(g.nta[1] * g.nta[2] * g.nseg), (unsigned)nplanes);
-    hipLaunchKernelGGL((interp_kernel<DIM, W>), blocks, dim3(GatherCfg<DIM, W>::NT), 0, stream, g, to, perm, spos, grid, (int)Cr,
-                       (int)plane0, yr);
+    if constexpr (DIM == 3) {
+        if (g.wide) {
+            hipLaunchKernelGGL((interp_kernel<DIM, W, true>), blocks, dim3(GatherCfg<DIM, W, true>::NT), 0, stream, g, to,
+                               perm, spos, grid, (int)Cr, (int)plane0, yr);
+            NFFT_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+    }
+    hipLaunchKernelGGL((interp_kernel<DIM, W, false>), blocks, dim3(GatherCfg<DIM, W, false>::NT), 0, stream, g, to, perm,
+                       spos, grid, (int)Cr, (int)plane0, yr);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }

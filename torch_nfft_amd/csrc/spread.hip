@@ -54,8 +54,13 @@ spread_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *_
 
     const int k_begin = seg * kSegChunks;
     const int k_end = min(g.nta[0], k_begin + kSegChunks);
-    const int tile0 = b * g.tiles_per_batch + pencil * g.nta[0];
-    if (tile_offsets[(tile0 + k_begin) * g.SB] == tile_offsets[(tile0 + k_end) * g.SB]) return;  // no points in this segment
+    const int bin0 = b * g.tiles_per_batch + pencil * g.np0;  // first plan bin of this pencil
+    {
+        int s0, e0, s1, e1;
+        chunk_range(g, tile_offsets, bin0, k_begin, s0, e0);
+        chunk_range(g, tile_offsets, bin0, k_end - 1, s1, e1);
+        if (s0 == e1) return;  // no points in this segment
+    }  // no points in this segment
 
     for (int i = tid; i < C::CELLS; i += NT) acc[i] = 0.0;
 
@@ -112,7 +117,8 @@ spread_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *_
 
     __syncthreads();
     for (int k = k_begin; k < k_end; ++k) {
-        const int s = tile_offsets[(tile0 + k) * g.SB], e = tile_offsets[(tile0 + k + 1) * g.SB];
+        int s, e;
+        chunk_range(g, tile_offsets, bin0, k, s, e);
         if (e == s) continue;
         const int want_z = k * C::TC - C::M0OFF;
         if (live && want_z != base_z) retire(min(want_z - base_z, C::NP));

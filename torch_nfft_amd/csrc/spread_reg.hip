@@ -108,7 +108,7 @@ spread_reg_kernel(const Geom g, const int *__restrict__ tile_offsets, const floa
             for (int d2 = -1; d2 <= 1; ++d2) {
                 const int nb2 = gs2 + d2 < 0 ? gs2 + d2 + nsb2 : (gs2 + d2 >= nsb2 ? gs2 + d2 - nsb2 : gs2 + d2);
                 const int J2 = nb2 / g.sb2, s2 = nb2 - J2 * g.sb2;
-                const int tile = b * g.tiles_per_batch + (J1 * g.nta[2] + J2) * nt0 + k;
+                const int tile = b * g.tiles_per_batch + (J1 * g.nta[2] + J2) * g.np0 + k;
                 const int fine = tile * g.SB + s1 * g.sb2 + s2;
                 const int s = tile_offsets[fine], e = tile_offsets[fine + 1];
                 // cell coordinates of that sub-block relative to the owned column
