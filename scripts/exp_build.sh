@@ -1,16 +1,16 @@
 #!/bin/bash
-# Developer tool: build variant libraries scripts/ubench/libnfft_<name>.so from an experimental copy of one kernel file.
-# usage: scripts/exp_build.sh <experimental.hip> <file in torch_nfft_amd/csrc it replaces> name1:"-DX=1" ...
+# Developer tool: build variant libraries scripts/ubench/libnfft_<name>.so from experimental copies of one kernel file.
+# usage: scripts/exp_build.sh <file in torch_nfft_amd/csrc it replaces> name1:<experimental.hip>:"-DX=1" ...
+# (the other objects come from torch_nfft_amd/_obj, i.e. run torch_nfft_amd/build.py first)
 set -e
-SRC=$1; shift; REPL=$1; shift
-BASE=$REPL
+BASE=$1; shift
 OBJS=""
-for f in api.hip binning.hip spread.hip interp.hip spectral.hip fft.cpp; do
+for f in api.hip binning.hip spread.hip spread_reg.hip spread_mfma.hip interp.hip spectral.hip colfft.hip coeffs.hip fft.cpp; do
   if [ "$f" != "$BASE" ]; then OBJS="$OBJS torch_nfft_amd/_obj/$f.o"; fi
 done
 for spec in "$@"; do
-  name=${spec%%:*}; flags=${spec#*:}
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -ffp-contract=fast $flags -Itorch_nfft_amd/csrc -I/opt/rocm/include -x hip -c $SRC -o /tmp/exp_$name.o && \
+  name=${spec%%:*}; rest=${spec#*:}; src=${rest%%:*}; flags=${rest#*:}
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -ffp-contract=fast -fno-slp-vectorize $flags -Itorch_nfft_amd/csrc -I/opt/rocm/include -x hip -c $src -o /tmp/exp_$name.o && \
     /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o scripts/ubench/libnfft_$name.so $OBJS /tmp/exp_$name.o -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib ) &
 done
 wait

@@ -40,18 +40,29 @@ constexpr int kMaxSegSlabs = 128;
 constexpr float kOpScale = 2048.0f;
 constexpr int kPsiStride = 20; // floats per row of the psi1 table (16 + 4: conflict-free ds_read_b128 over rows)
 
-struct KbInfo { int slab, start, cnt, pad; };
-
+// Operands of one batch of K-blocks, double-buffered: while the waves run the MFMAs of batch i they already build
+// the operands of batch i + 1.
 template <int W>
-struct __align__(16) MfmaLds {
+struct __align__(16) MfmaOps {
     f16x8 bfrag[kNKB][2][2][64];          // [K-block][column tile][hi/lo][lane]
     float psi1[kNKB][32][kPsiStride];     // [K-block][row][point]
     float atab[kNKB][W][kKB];             // [K-block][axis-0 tap][point]   x' * psi0
-    float pg1[kSlots], pg2[kSlots], pf0[kSlots], px[kSlots];
-    int pc1[kSlots], pc2[kSlots];
-    KbInfo kb[kNKB];
+    int slab[kNKB];
+};
+
+// Points of one batch (cell fractions, in-pencil cells, scaled value), double-buffered as well.
+struct __align__(16) MfmaStage {
+    float f0[kSlots], f1[kSlots], f2[kSlots], x[kSlots];
+    int c1[kSlots], c2[kSlots];
+    int slab[kNKB];
+};
+
+template <int W>
+struct __align__(16) MfmaLds {
+    MfmaOps<W> ops[2];
+    MfmaStage stag[2];
     int soff[kMaxSegSlabs + 1];           // point offsets of the segment's slabs
-    int nkb, cur_slab, cur_pos, done;
+    int kbp[kMaxSegSlabs + 1];            // K-blocks before each slab (a slab's last K-block may be partial)
 };
 
 template <int W>
@@ -61,7 +72,8 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                    const int plane0, float *__restrict__ grid, const int seg_slabs, const int nsegm)
 {
     constexpr int m = W / 2 - 1;
-    __shared__ MfmaLds<W> L;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    MfmaLds<W> &L = *reinterpret_cast<MfmaLds<W> *>(smem_raw);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -79,6 +91,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
 
     const int sb = seg * seg_slabs;
     const int se = min(g.M, sb + seg_slabs);
+    const int nslab = se - sb;
     const int bin0 = b * g.tiles_per_batch + pencil * g.np0;  // np0 == M: one plan bin per slab
     if (tile_offsets[bin0 + sb] == tile_offsets[bin0 + se]) return;
 
@@ -128,61 +141,73 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
         }
     };
 
-    for (int i = tid; i <= se - sb; i += kMfmaThreads) L.soff[i] = tile_offsets[bin0 + sb + i];
-    if (tid == 0) {
-        L.cur_slab = sb;
-        L.cur_pos = tile_offsets[bin0 + sb];
-        L.done = 0;
+    // ---- K-block schedule: slab s holds ceil(count / 16) K-blocks; kbp = their exclusive prefix sums -----------
+    for (int i = tid; i <= nslab; i += kMfmaThreads) L.soff[i] = tile_offsets[bin0 + sb + i];
+    __syncthreads();
+    if (wave == 0) {
+        const int s0 = 2 * lane, s1 = s0 + 1;
+        const int n0 = s0 < nslab ? (L.soff[s0 + 1] - L.soff[s0] + kKB - 1) / kKB : 0;
+        const int n1 = s1 < nslab ? (L.soff[s1 + 1] - L.soff[s1] + kKB - 1) / kKB : 0;
+        int incl = n0 + n1;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        const int excl = incl - (n0 + n1);
+        L.kbp[s0] = excl;
+        L.kbp[s1] = excl + n0;
+        if (lane == 63) L.kbp[kMaxSegSlabs] = incl;
     }
     __syncthreads();
+    const int total = L.kbp[nslab];
+    const int nbatch = (total + kNKB - 1) / kNKB;
 
-    while (true) {
-        // ---- B0: next batch of K-blocks (16 points of one slab each) --------------------------------------
-        if (tid == 0) {
-            int s = L.cur_slab, pos = L.cur_pos, nkb = 0;
-            while (nkb < kNKB && s < se) {
-                const int end = L.soff[s + 1 - sb];
-                if (pos >= end) { ++s; continue; }
-                const int cnt = min(kKB, end - pos);
-                L.kb[nkb].slab = s;
-                L.kb[nkb].start = pos;
-                L.kb[nkb].cnt = cnt;
-                ++nkb;
-                pos += cnt;
+    // ---- staging of a batch: thread -> (K-block, point); the loads are issued one pipeline step ahead ---------
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f, rx = 0.f;
+    int rslab = INT_MAX;
+    bool rhave = false;
+    auto stage_load = [&](const int batch) {
+        const int j = tid / kKB, i = tid - j * kKB;
+        const int q = batch * kNKB + j;
+        rslab = INT_MAX;
+        rhave = false;
+        if (q < total) {
+            int lo = 0, hi = nslab;  // kbp[lo] <= q < kbp[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (L.kbp[mid] <= q) lo = mid; else hi = mid;
             }
-            L.nkb = nkb;
-            L.cur_slab = s;
-            L.cur_pos = pos;
-            if (nkb == 0) L.done = 1;
-        }
-        __syncthreads();
-        if (L.done) break;
-        const int nkb = L.nkb;
-
-        // ---- B1: stage the points of the batch ------------------------------------------------------------
-        if (tid < nkb * kKB) {
-            const int j = tid / kKB, i = tid - j * kKB;
-            float g1 = 0.f, g2 = 0.f, f0 = 0.f, xv = 0.f;
-            int c1 = -1000, c2 = -1000;  // padding slots: outside every window
-            if (i < L.kb[j].cnt) {
-                const int64_t idx = (int64_t)L.kb[j].start + i;
-                int c0;
-                float f1, f2;
-                split_cell(spos[idx * 3 + 0], g.M, c0, f0);
-                split_cell(spos[idx * 3 + 1], g.M, c1, f1);
-                split_cell(spos[idx * 3 + 2], g.M, c2, f2);
-                c1 -= tb1 - m;  // row of the point's cell inside the padded pencil (tap l1 sits at row c1 - m + l1)
-                c2 -= tb2 - m;
-                g1 = f1 + (float)c1;
-                g2 = f2 + (float)c2;
-                xv = xcol[idx] * inv_xscale;
+            const int start = L.soff[lo] + kKB * (q - L.kbp[lo]);
+            rslab = sb + lo;
+            if (start + i < L.soff[lo + 1]) {
+                const int64_t idx = (int64_t)start + i;
+                r0 = spos[idx * 3 + 0];
+                r1 = spos[idx * 3 + 1];
+                r2 = spos[idx * 3 + 2];
+                rx = xcol[idx];
+                rhave = true;
             }
-            L.pg1[tid] = g1; L.pg2[tid] = g2; L.pf0[tid] = f0; L.px[tid] = xv;
-            L.pc1[tid] = c1; L.pc2[tid] = c2;
         }
-        __syncthreads();
+    };
+    auto stage_store = [&](MfmaStage &S) {
+        float f0 = 0.f, f1 = 0.f, f2 = 0.f, xv = 0.f;
+        int c1 = -1000, c2 = -1000;  // padding slots: outside every window
+        if (rhave) {
+            int c0;
+            split_cell(r0, g.M, c0, f0);
+            split_cell(r1, g.M, c1, f1);
+            split_cell(r2, g.M, c2, f2);
+            c1 -= tb1 - m;  // row of the point's cell inside the padded pencil (tap l1 sits at row c1 - m + l1)
+            c2 -= tb2 - m;
+            xv = rx * inv_xscale;
+        }
+        S.f0[tid] = f0; S.f1[tid] = f1; S.f2[tid] = f2; S.x[tid] = xv;
+        S.c1[tid] = c1; S.c2[tid] = c2;
+        if ((tid & (kKB - 1)) == 0) S.slab[tid / kKB] = rslab;
+    };
 
-        // ---- B2: operands ----------------------------------------------------------------------------------
+    // ---- operands of a batch ---------------------------------------------------------------------------------
+    auto build_operands = [&](const MfmaStage &S, MfmaOps<W> &O, const int nkb) {
         // B fragments: thread -> (K-block, column tile, lane): 8 points of one column, split into f16 hi / lo
         for (int task = tid; task < nkb * 128; task += kMfmaThreads) {
             const int j = task >> 7, t = (task >> 6) & 1, ln = task & 63;
@@ -191,16 +216,18 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
                 const int slot = j * kKB + k0 + jj;
-                const float d = L.pg2[slot] - (float)col;
-                const int l2 = col - L.pc2[slot] + m;
+                const int dc = S.c2[slot] - col;  // distance = fraction + whole cells, exact in fp32
+                const float d = S.f2[slot] + (float)dc;
+                const int l2 = m - dc;
                 float v = __builtin_amdgcn_exp2f(sc * d * d) * kOpScale;
                 v = (unsigned)l2 < (unsigned)W ? v : 0.0f;
+                asm volatile("" : "+v"(v));  // see the A fragments below
                 const _Float16 vh = (_Float16)v;
                 hi[jj] = vh;
                 lo[jj] = (_Float16)(v - (float)vh);
             }
-            L.bfrag[j][t][0][ln] = hi;
-            L.bfrag[j][t][1][ln] = lo;
+            O.bfrag[j][t][0][ln] = hi;
+            O.bfrag[j][t][1][ln] = lo;
         }
         // psi1 table: thread -> (K-block, row, half): 8 points
         for (int task = tid; task < nkb * 64; task += kMfmaThreads) {
@@ -208,10 +235,11 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
                 const int slot = j * kKB + k0 + jj;
-                const float d = L.pg1[slot] - (float)row;
-                const int l1 = row - L.pc1[slot] + m;
+                const int dc = S.c1[slot] - row;
+                const float d = S.f1[slot] + (float)dc;
+                const int l1 = m - dc;
                 const float v = __builtin_amdgcn_exp2f(sc * d * d);
-                L.psi1[j][row][k0 + jj] = (unsigned)l1 < (unsigned)W ? v : 0.0f;
+                O.psi1[j][row][k0 + jj] = (unsigned)l1 < (unsigned)W ? v : 0.0f;
             }
         }
         // axis-0 table: thread -> (K-block, tap, point)
@@ -219,14 +247,16 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
             const int j = task / (W * kKB), rem = task - j * (W * kKB);
             const int l0 = rem / kKB, k = rem - l0 * kKB;
             const int slot = j * kKB + k;
-            const float d = L.pf0[slot] + (float)(m - l0);
-            L.atab[j][l0][k] = L.px[slot] * __builtin_amdgcn_exp2f(sc * d * d) * kOpScale;
+            const float d = S.f0[slot] + (float)(m - l0);
+            O.atab[j][l0][k] = S.x[slot] * __builtin_amdgcn_exp2f(sc * d * d) * kOpScale;
         }
-        __syncthreads();
+        if (tid < kNKB) O.slab[tid] = S.slab[tid];
+    };
 
-        // ---- B3: every wave adds the K-blocks that reach its plane ---------------------------------------
+    // ---- every wave adds the K-blocks that reach its plane -------------------------------------------------
+    auto accumulate = [&](const MfmaOps<W> &O, const int nkb) {
         for (int j = 0; j < nkb; ++j) {
-            const int s = L.kb[j].slab;
+            const int s = O.slab[j];
             // the sweep has passed plane myz once the current slab is beyond myz + m
             while (myz + m < s) {
                 flush();
@@ -234,20 +264,24 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
             }
             const int l0 = myz - s + m;  // axis-0 tap of this K-block's points that lands on my plane
             if ((unsigned)l0 < (unsigned)W) {
-                const f32x4 *pp = (const f32x4 *)&L.psi1[j][r32][8 * h];
-                const f32x4 *pa = (const f32x4 *)&L.atab[j][l0][8 * h];
+                const f32x4 *pp = (const f32x4 *)&O.psi1[j][r32][8 * h];
+                const f32x4 *pa = (const f32x4 *)&O.atab[j][l0][8 * h];
                 const f32x4 p0 = pp[0], p1 = pp[1], a0 = pa[0], a1 = pa[1];
-                const float v[8] = {p0.x * a0.x, p0.y * a0.y, p0.z * a0.z, p0.w * a0.w,
-                                    p1.x * a1.x, p1.y * a1.y, p1.z * a1.z, p1.w * a1.w};
+                float v[8] = {p0.x * a0.x, p0.y * a0.y, p0.z * a0.z, p0.w * a0.w,
+                              p1.x * a1.x, p1.y * a1.y, p1.z * a1.z, p1.w * a1.w};
                 f16x8 ah, al;
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
+                    // opaque to the optimiser: hi must be the f16 rounding of the SAME fp32 value the residual is
+                    // taken from (under -ffp-contract=fast the residual is otherwise fused against a separately
+                    // rounded product and ends up one f16 ulp off near ties)
+                    asm volatile("" : "+v"(v[jj]));
                     const _Float16 vh = (_Float16)v[jj];
                     ah[jj] = vh;
                     al[jj] = (_Float16)(v[jj] - (float)vh);
                 }
-                const f16x8 b0h = L.bfrag[j][0][0][lane], b0l = L.bfrag[j][0][1][lane];
-                const f16x8 b1h = L.bfrag[j][1][0][lane], b1l = L.bfrag[j][1][1][lane];
+                const f16x8 b0h = O.bfrag[j][0][0][lane], b0l = O.bfrag[j][0][1][lane];
+                const f16x8 b1h = O.bfrag[j][1][0][lane], b1l = O.bfrag[j][1][1][lane];
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0h, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1h, acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0l, acc0, 0, 0, 0);
@@ -257,6 +291,22 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                 dirty = true;
             }
         }
+    };
+
+    // ---- software pipeline, one barrier per batch: step i loads the points of batch i + 2 into registers, builds
+    // the operands of batch i + 1 (buffer (i+1)&1) and runs the MFMAs of batch i (buffer i&1); the loaded points go
+    // to the staging buffer batch i used (its last reader, step i - 1, is behind the previous barrier).
+    if (tid < kSlots) {
+        stage_load(0);
+        stage_store(L.stag[0]);
+    }
+    __syncthreads();
+    for (int i = -1; i < nbatch; ++i) {
+        const bool have2 = i + 2 < nbatch && tid < kSlots;
+        if (have2) stage_load(i + 2);
+        if (i + 1 < nbatch) build_operands(L.stag[(i + 1) & 1], L.ops[(i + 1) & 1], min(kNKB, total - (i + 1) * kNKB));
+        if (i >= 0) accumulate(L.ops[i & 1], min(kNKB, total - i * kNKB));
+        if (have2) stage_store(L.stag[i & 1]);
         __syncthreads();
     }
     flush();
@@ -274,7 +324,13 @@ static int launch_mfma_t(const Geom &g, const int *to, const float *spos, const 
     if (seg_slabs > g.M) seg_slabs = g.M;
     const int nsegm = (g.M + seg_slabs - 1) / seg_slabs;
     const dim3 blocks((unsigned)(g.nta[1] * g.nta[2] * nsegm), (unsigned)nplanes);
-    hipLaunchKernelGGL((spread_mfma_kernel<W>), blocks, dim3(kMfmaThreads), 0, stream, g, to, spos, xs, maxabs, n,
+    static bool attr_done = false;  // one workgroup per CU: the double-buffered operands take most of the 160 KB LDS
+    if (!attr_done) {
+        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)spread_mfma_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)sizeof(MfmaLds<W>)));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((spread_mfma_kernel<W>), blocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to, spos, xs, maxabs, n,
                        (int)Cr, (int)plane0, grid, seg_slabs, nsegm);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
