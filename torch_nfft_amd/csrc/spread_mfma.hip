@@ -51,6 +51,49 @@ struct __align__(16) MfmaOps {
 };
 
 // Points of one batch (cell fractions, in-pencil cells, scaled value), double-buffered as well.
+// Two-way f16 split of fp32 values in three VALU instructions per pair: hi = RN16(RN32(v)), lo = RN16(v - hi) with
+// the subtraction done by the mixed-precision FMA against the hi that is actually used (letting the compiler fuse
+// the residual under -ffp-contract=fast pairs it with a differently rounded hi: one f16 ulp off near ties).
+__device__ __forceinline__ void split_pair(const float v0, const float v1, unsigned &hi, unsigned &lo)
+{
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(hi), "=&v"(lo)
+        : "v"(v0), "v"(v1));
+}
+
+// The same for products p * a: hi = RN16(p a), lo = RN16(p a - hi), both from the exact product (4 instructions).
+__device__ __forceinline__ void split_product_pair(const float p0, const float a0, const float p1, const float a1,
+                                                   unsigned &hi, unsigned &lo)
+{
+    asm("v_fma_mixlo_f16 %0, %2, %3, 0\n\t"
+        "v_fma_mixhi_f16 %0, %4, %5, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %3, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %4, %5, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(hi), "=&v"(lo)
+        : "v"(p0), "v"(a0), "v"(p1), "v"(a1));
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// One dword per active lane, global -> LDS without a register in between (LDS-DMA): lane l of the wave lands at
+// lds_wave_base + 4 l.  Issued through asm so that the compiler does not drain it (vmcnt(0)) at the next LDS read or
+// barrier; the consumer waits with wait_lds_dma() one pipeline step later.
+__device__ __forceinline__ void lds_dma_dword(const float *gsrc, const float *lds_wave_base)
+{
+    const unsigned lds = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds)
+                 : "memory");
+}
+__device__ __forceinline__ void wait_lds_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// workgroup barrier that leaves global traffic (LDS-DMA, flush atomics) in flight
+__device__ __forceinline__ void barrier_lds_only() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct __align__(16) MfmaStage {
     float f0[kSlots], f1[kSlots], f2[kSlots], x[kSlots];
     int c1[kSlots], c2[kSlots];
@@ -61,12 +104,15 @@ template <int W>
 struct __align__(16) MfmaLds {
     MfmaOps<W> ops[2];
     MfmaStage stag[2];
-    int soff[kMaxSegSlabs + 1];           // point offsets of the segment's slabs
-    int kbp[kMaxSegSlabs + 1];            // K-blocks before each slab (a slab's last K-block may be partial)
+    float raw[4][kSlots];                 // landing zone of the LDS-DMA: pos0, pos1, pos2, x of the next batch
+    int raw_have[kSlots];
+    int raw_slab[kNKB];
+    int task_counter[2];
+    int2 sched[kMaxSegSlabs + 8];         // per slab: {K-blocks before it, point offset}; padded with the totals
 };
 
 template <int W>
-__global__ void __launch_bounds__(kMfmaThreads)
+__global__ void __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *__restrict__ spos,
                    const float *__restrict__ xs, const float *__restrict__ maxabs, const int64_t n, const int Cr,
                    const int plane0, float *__restrict__ grid, const int seg_slabs, const int nsegm)
@@ -141,122 +187,146 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
         }
     };
 
-    // ---- K-block schedule: slab s holds ceil(count / 16) K-blocks; kbp = their exclusive prefix sums -----------
-    for (int i = tid; i <= nslab; i += kMfmaThreads) L.soff[i] = tile_offsets[bin0 + sb + i];
-    __syncthreads();
+    // ---- K-block schedule: slab s holds ceil(count / 16) K-blocks; sched[s] = {K-blocks before s, point offset} ---
     if (wave == 0) {
         const int s0 = 2 * lane, s1 = s0 + 1;
-        const int n0 = s0 < nslab ? (L.soff[s0 + 1] - L.soff[s0] + kKB - 1) / kKB : 0;
-        const int n1 = s1 < nslab ? (L.soff[s1 + 1] - L.soff[s1] + kKB - 1) / kKB : 0;
+        const int o0 = tile_offsets[bin0 + sb + min(s0, nslab)];
+        const int o1 = tile_offsets[bin0 + sb + min(s1, nslab)];
+        const int o2 = tile_offsets[bin0 + sb + min(s1 + 1, nslab)];
+        const int n0 = (o1 - o0 + kKB - 1) / kKB, n1 = (o2 - o1 + kKB - 1) / kKB;  // 0 beyond the segment
         int incl = n0 + n1;
         for (int off = 1; off < 64; off <<= 1) {
             const int t = __shfl_up(incl, off);
             if (lane >= off) incl += t;
         }
         const int excl = incl - (n0 + n1);
-        L.kbp[s0] = excl;
-        L.kbp[s1] = excl + n0;
-        if (lane == 63) L.kbp[kMaxSegSlabs] = incl;
+        L.sched[s0] = make_int2(excl, o0);
+        L.sched[s1] = make_int2(excl + n0, o1);
+        if (lane == 63)
+            for (int t = 0; t < 8; ++t) L.sched[kMaxSegSlabs + t] = make_int2(incl, o2);
     }
     __syncthreads();
-    const int total = L.kbp[nslab];
+    const int total = L.sched[nslab].x;
     const int nbatch = (total + kNKB - 1) / kNKB;
 
-    // ---- staging of a batch: thread -> (K-block, point); the loads are issued one pipeline step ahead ---------
-    float r0 = 0.f, r1 = 0.f, r2 = 0.f, rx = 0.f;
-    int rslab = INT_MAX;
-    bool rhave = false;
-    auto stage_load = [&](const int batch) {
+    // ---- staging of a batch: thread -> (K-block, point).  The points of batch i + 3 are requested (LDS-DMA into
+    // L.raw) while batch i is accumulated, and converted to (cell, fraction) form one step later.
+    int cur = 0;  // slab of this thread's previous K-block (K-blocks only move forward)
+    auto stage_request = [&](const int batch) {
         const int j = tid / kKB, i = tid - j * kKB;
         const int q = batch * kNKB + j;
-        rslab = INT_MAX;
-        rhave = false;
+        int have = 0, slab = INT_MAX;
         if (q < total) {
-            int lo = 0, hi = nslab;  // kbp[lo] <= q < kbp[hi]
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (L.kbp[mid] <= q) lo = mid; else hi = mid;
+            // sched[lo].x <= q < sched[lo + 1].x; probe four slabs ahead per LDS round trip
+            int lo = cur;
+            int2 e0, e1;
+            while (true) {
+                const int2 c0 = L.sched[lo], c1 = L.sched[lo + 1], c2 = L.sched[lo + 2], c3 = L.sched[lo + 3],
+                           c4 = L.sched[lo + 4];
+                if (q < c1.x) { e0 = c0; e1 = c1; break; }
+                if (q < c2.x) { e0 = c1; e1 = c2; lo += 1; break; }
+                if (q < c3.x) { e0 = c2; e1 = c3; lo += 2; break; }
+                if (q < c4.x) { e0 = c3; e1 = c4; lo += 3; break; }
+                lo += 4;
             }
-            const int start = L.soff[lo] + kKB * (q - L.kbp[lo]);
-            rslab = sb + lo;
-            if (start + i < L.soff[lo + 1]) {
-                const int64_t idx = (int64_t)start + i;
-                r0 = spos[idx * 3 + 0];
-                r1 = spos[idx * 3 + 1];
-                r2 = spos[idx * 3 + 2];
-                rx = xcol[idx];
-                rhave = true;
+            cur = lo;
+            slab = sb + lo;
+            const int idx = e0.y + kKB * (q - e0.x) + i;
+            have = idx < e1.y;
+            if (have) {
+                lds_dma_dword(spos + (int64_t)idx * 3 + 0, &L.raw[0][wave * 64]);
+                lds_dma_dword(spos + (int64_t)idx * 3 + 1, &L.raw[1][wave * 64]);
+                lds_dma_dword(spos + (int64_t)idx * 3 + 2, &L.raw[2][wave * 64]);
+                lds_dma_dword(xcol + idx, &L.raw[3][wave * 64]);
             }
         }
+        L.raw_have[tid] = have;
+        if (i == 0) L.raw_slab[j] = slab;
     };
-    auto stage_store = [&](MfmaStage &S) {
+    auto stage_convert = [&](MfmaStage &S) {
+        wait_lds_dma();
         float f0 = 0.f, f1 = 0.f, f2 = 0.f, xv = 0.f;
         int c1 = -1000, c2 = -1000;  // padding slots: outside every window
-        if (rhave) {
+        if (L.raw_have[tid]) {
             int c0;
-            split_cell(r0, g.M, c0, f0);
-            split_cell(r1, g.M, c1, f1);
-            split_cell(r2, g.M, c2, f2);
+            split_cell(L.raw[0][tid], g.M, c0, f0);
+            split_cell(L.raw[1][tid], g.M, c1, f1);
+            split_cell(L.raw[2][tid], g.M, c2, f2);
             c1 -= tb1 - m;  // row of the point's cell inside the padded pencil (tap l1 sits at row c1 - m + l1)
             c2 -= tb2 - m;
-            xv = rx * inv_xscale;
+            xv = L.raw[3][tid] * inv_xscale;
         }
         S.f0[tid] = f0; S.f1[tid] = f1; S.f2[tid] = f2; S.x[tid] = xv;
         S.c1[tid] = c1; S.c2[tid] = c2;
-        if ((tid & (kKB - 1)) == 0) S.slab[tid / kKB] = rslab;
+        if ((tid & (kKB - 1)) == 0) S.slab[tid / kKB] = L.raw_slab[tid / kKB];  // written by this same thread
     };
 
-    // ---- operands of a batch ---------------------------------------------------------------------------------
-    auto build_operands = [&](const MfmaStage &S, MfmaOps<W> &O, const int nkb) {
-        // B fragments: thread -> (K-block, column tile, lane): 8 points of one column, split into f16 hi / lo
-        for (int task = tid; task < nkb * 128; task += kMfmaThreads) {
-            const int j = task >> 7, t = (task >> 6) & 1, ln = task & 63;
-            const int col = 32 * t + (ln & 31), k0 = 8 * (ln >> 5);
-            f16x8 hi, lo;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const int slot = j * kKB + k0 + jj;
-                const int dc = S.c2[slot] - col;  // distance = fraction + whole cells, exact in fp32
-                const float d = S.f2[slot] + (float)dc;
-                const int l2 = m - dc;
-                float v = __builtin_amdgcn_exp2f(sc * d * d) * kOpScale;
-                v = (unsigned)l2 < (unsigned)W ? v : 0.0f;
-                asm volatile("" : "+v"(v));  // see the A fragments below
-                const _Float16 vh = (_Float16)v;
-                hi[jj] = vh;
-                lo[jj] = (_Float16)(v - (float)vh);
+    // ---- operands of a batch: three wave-sized tasks per K-block, handed out through an LDS counter so that the
+    // waves whose plane lies outside the batch's windows (6 of 16 for m = 4) build them while the others run MFMAs.
+    // Only the 16 (2m+2) taps per axis are evaluated and scattered into zero-filled tables.
+    auto build_tasks = [&](const MfmaStage &S, MfmaOps<W> &O, const int nkb, int *counter) {
+        while (true) {
+            // all 64 lanes add 1 (the compiler folds this into one ds_add of 64 per wave): the counter runs in units of
+            // 64, lane 0 sees the wave's base value
+            const int t = __builtin_amdgcn_readfirstlane(atomicAdd(counter, 1)) >> 6;
+            if (t >= 3 * nkb) break;
+            const int j = t / 3, kind = t - 3 * j;
+            if (kind == 0) {
+                // B fragments [column tile][hi/lo][lane = 32 (k / 8) + column] element k % 8, f16 hi / lo of psi2
+                const f16x8 zero = (_Float16)0.0f;
+                O.bfrag[j][0][0][lane] = zero;
+                O.bfrag[j][0][1][lane] = zero;
+                O.bfrag[j][1][0][lane] = zero;
+                O.bfrag[j][1][1][lane] = zero;
+                asm volatile("" ::: "memory");  // the 16-bit scatter below must stay behind the zero fill
+                for (int e = lane; e < W * kKB; e += 64) {
+                    const int k = e / W, l = e - k * W;
+                    const int slot = j * kKB + k;
+                    const int col = S.c2[slot] - m + l;
+                    const float d = S.f2[slot] + (float)(m - l);
+                    const float v = __builtin_amdgcn_exp2f(sc * d * d) * kOpScale;
+                    unsigned hi, lo;
+                    split_pair(v, 0.0f, hi, lo);
+                    if ((unsigned)col < 64u) {  // padding slots fail this
+                        const int ln = 32 * (k >> 3) + (col & 31);
+                        _Float16 *ph = (_Float16 *)&O.bfrag[j][col >> 5][0][ln];
+                        _Float16 *pl = (_Float16 *)&O.bfrag[j][col >> 5][1][ln];
+                        ph[k & 7] = __builtin_bit_cast(_Float16, (unsigned short)hi);
+                        pl[k & 7] = __builtin_bit_cast(_Float16, (unsigned short)lo);
+                    }
+                }
+            } else if (kind == 1) {
+                // psi1 table [row][point]
+                f32x4 *pz = (f32x4 *)&O.psi1[j][0][0];
+                const f32x4 zero = 0.0f;
+                for (int e = lane; e < 32 * kPsiStride / 4; e += 64) pz[e] = zero;
+                asm volatile("" ::: "memory");
+                for (int e = lane; e < W * kKB; e += 64) {
+                    const int k = e / W, l = e - k * W;
+                    const int slot = j * kKB + k;
+                    const int row = S.c1[slot] - m + l;
+                    const float d = S.f1[slot] + (float)(m - l);
+                    const float v = __builtin_amdgcn_exp2f(sc * d * d);
+                    if ((unsigned)row < 32u) O.psi1[j][row][k] = v;
+                }
+            } else {
+                // axis-0 table [tap][point]: x' psi0
+                for (int e = lane; e < W * kKB; e += 64) {
+                    const int l0 = e / kKB, k = e - l0 * kKB;
+                    const int slot = j * kKB + k;
+                    const float d = S.f0[slot] + (float)(m - l0);
+                    O.atab[j][l0][k] = S.x[slot] * __builtin_amdgcn_exp2f(sc * d * d) * kOpScale;
+                }
+                if (lane == 0) O.slab[j] = S.slab[j];
             }
-            O.bfrag[j][t][0][ln] = hi;
-            O.bfrag[j][t][1][ln] = lo;
         }
-        // psi1 table: thread -> (K-block, row, half): 8 points
-        for (int task = tid; task < nkb * 64; task += kMfmaThreads) {
-            const int j = task >> 6, row = task & 31, k0 = 8 * ((task >> 5) & 1);
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const int slot = j * kKB + k0 + jj;
-                const int dc = S.c1[slot] - row;
-                const float d = S.f1[slot] + (float)dc;
-                const int l1 = m - dc;
-                const float v = __builtin_amdgcn_exp2f(sc * d * d);
-                O.psi1[j][row][k0 + jj] = (unsigned)l1 < (unsigned)W ? v : 0.0f;
-            }
-        }
-        // axis-0 table: thread -> (K-block, tap, point)
-        for (int task = tid; task < nkb * W * kKB; task += kMfmaThreads) {
-            const int j = task / (W * kKB), rem = task - j * (W * kKB);
-            const int l0 = rem / kKB, k = rem - l0 * kKB;
-            const int slot = j * kKB + k;
-            const float d = S.f0[slot] + (float)(m - l0);
-            O.atab[j][l0][k] = S.x[slot] * __builtin_amdgcn_exp2f(sc * d * d) * kOpScale;
-        }
-        if (tid < kNKB) O.slab[tid] = S.slab[tid];
     };
 
     // ---- every wave adds the K-blocks that reach its plane -------------------------------------------------
     auto accumulate = [&](const MfmaOps<W> &O, const int nkb) {
+        const int slabs = O.slab[lane & (kNKB - 1)];  // one LDS read; K-block j's slab by readlane
         for (int j = 0; j < nkb; ++j) {
-            const int s = O.slab[j];
+            const int s = __builtin_amdgcn_readlane(slabs, j);
             // the sweep has passed plane myz once the current slab is beyond myz + m
             while (myz + m < s) {
                 flush();
@@ -267,19 +337,13 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                 const f32x4 *pp = (const f32x4 *)&O.psi1[j][r32][8 * h];
                 const f32x4 *pa = (const f32x4 *)&O.atab[j][l0][8 * h];
                 const f32x4 p0 = pp[0], p1 = pp[1], a0 = pa[0], a1 = pa[1];
-                float v[8] = {p0.x * a0.x, p0.y * a0.y, p0.z * a0.z, p0.w * a0.w,
-                              p1.x * a1.x, p1.y * a1.y, p1.z * a1.z, p1.w * a1.w};
-                f16x8 ah, al;
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    // opaque to the optimiser: hi must be the f16 rounding of the SAME fp32 value the residual is
-                    // taken from (under -ffp-contract=fast the residual is otherwise fused against a separately
-                    // rounded product and ends up one f16 ulp off near ties)
-                    asm volatile("" : "+v"(v[jj]));
-                    const _Float16 vh = (_Float16)v[jj];
-                    ah[jj] = vh;
-                    al[jj] = (_Float16)(v[jj] - (float)vh);
-                }
+                unsigned h0, h1, h2, h3, q0, q1, q2, q3;
+                split_product_pair(p0.x, a0.x, p0.y, a0.y, h0, q0);
+                split_product_pair(p0.z, a0.z, p0.w, a0.w, h1, q1);
+                split_product_pair(p1.x, a1.x, p1.y, a1.y, h2, q2);
+                split_product_pair(p1.z, a1.z, p1.w, a1.w, h3, q3);
+                const u32x4 uh = {h0, h1, h2, h3}, ul = {q0, q1, q2, q3};
+                const f16x8 ah = __builtin_bit_cast(f16x8, uh), al = __builtin_bit_cast(f16x8, ul);
                 const f16x8 b0h = O.bfrag[j][0][0][lane], b0l = O.bfrag[j][0][1][lane];
                 const f16x8 b1h = O.bfrag[j][1][0][lane], b1l = O.bfrag[j][1][1][lane];
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0h, acc0, 0, 0, 0);
@@ -293,21 +357,27 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
         }
     };
 
-    // ---- software pipeline, one barrier per batch: step i loads the points of batch i + 2 into registers, builds
-    // the operands of batch i + 1 (buffer (i+1)&1) and runs the MFMAs of batch i (buffer i&1); the loaded points go
-    // to the staging buffer batch i used (its last reader, step i - 1, is behind the previous barrier).
+    // ---- software pipeline, one barrier per batch.  Step i: convert the points of batch i + 2 (requested in step
+    // i - 1) into staging buffer i & 1 (its last reader, build_operands of batch i in step i - 1, is behind the previous
+    // barrier), request batch i + 3, build the operands of batch i + 1 (buffer (i+1) & 1) and run the MFMAs of batch i.
+    if (tid < 2) L.task_counter[tid] = 0;
     if (tid < kSlots) {
-        stage_load(0);
-        stage_store(L.stag[0]);
+        stage_request(0);
+        stage_convert(L.stag[0]);
+        if (1 < nbatch) stage_request(1);
     }
     __syncthreads();
     for (int i = -1; i < nbatch; ++i) {
-        const bool have2 = i + 2 < nbatch && tid < kSlots;
-        if (have2) stage_load(i + 2);
-        if (i + 1 < nbatch) build_operands(L.stag[(i + 1) & 1], L.ops[(i + 1) & 1], min(kNKB, total - (i + 1) * kNKB));
+        if (tid < kSlots) {
+            if (i + 2 < nbatch) stage_convert(L.stag[i & 1]);
+            if (i + 3 < nbatch) stage_request(i + 3);
+        }
+        if (tid == 0) L.task_counter[i & 1] = 0;  // for the next step; its last user is behind the previous barrier
         if (i >= 0) accumulate(L.ops[i & 1], min(kNKB, total - i * kNKB));
-        if (have2) stage_store(L.stag[i & 1]);
-        __syncthreads();
+        if (i + 1 < nbatch)
+            build_tasks(L.stag[(i + 1) & 1], L.ops[(i + 1) & 1], min(kNKB, total - (i + 1) * kNKB),
+                        &L.task_counter[(i + 1) & 1]);
+        barrier_lds_only();
     }
     flush();
 }
