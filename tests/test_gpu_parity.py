@@ -389,6 +389,37 @@ print("RESULT", err, bool(torch.equal(y1, y2)))
     assert float(line[1]) < T1 and line[2] == "True"
 
 
+def test_lds_spreading_mode_matches_oracle():
+    """NFFT_HIP_SPREAD=lds keeps the f64-LDS-atomic spreading kernel and the narrow pencil tiling for 3-D grids that
+    would otherwise take the matrix-core kernel: adjoint and forward against the oracle."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+import torch_nfft_amd as tn
+from oracle import nfft_ref
+rng = np.random.default_rng(4)
+n, N, m = 4000, 32, 4
+pos = (rng.random((n, 3)) - 0.5).astype(np.float32)
+pos[:500] = (0.02 * rng.standard_normal((500, 3)) + 0.4999).astype(np.float32)
+x = rng.standard_normal((n, 2)).astype(np.float32)
+xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(pos).cuda()
+y = tn.nfft_adjoint(xt, pt, None, bandwidth=N, cutoff=m)
+ref = nfft_ref.nfft_adjoint(x, pos, None, N=N, m=m)
+e1 = np.linalg.norm(y.cpu().numpy() - ref) / np.linalg.norm(ref)
+f = tn.nfft_forward(y, pt, None, cutoff=m)
+reff = nfft_ref.nfft_forward(y.cpu().numpy(), pos, None, m=m)
+e2 = np.linalg.norm(f.cpu().numpy() - reff) / np.linalg.norm(reff)
+print("RESULT", e1, e2)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NFFT_HIP_SPREAD="lds")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    assert float(line[1]) < T1 and float(line[2]) < T1
+
+
 def test_clustered_points_many_per_tile(tn):
     """All points inside one grid cell neighbourhood: stresses LDS accumulation order and the chunk sweep."""
     rng = np.random.default_rng(71)

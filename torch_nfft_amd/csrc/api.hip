@@ -54,8 +54,8 @@ SpreadMode spread_mode()
     static const SpreadMode mode = [] {
         const char *env = std::getenv("NFFT_HIP_SPREAD");
         if (env && env[0] == 'r') return kSpreadReg;
-        if (env && env[0] == 'm') return kSpreadMfma;
-        return kSpreadLds;
+        if (env && env[0] == 'l') return kSpreadLds;
+        return kSpreadMfma;
     }();
     return mode;
 }

@@ -50,8 +50,9 @@ constexpr int kMaxW = 18;       // 2m+2 for m <= 8
 constexpr int kMaxCutoff = 8;
 
 // Spreading kernel for 3-D problems, chosen once per process by NFFT_HIP_SPREAD:
-//   lds  (spread.hip)       ds_add_f64 into LDS-resident planes
-//   mfma (spread_mfma.hip)  per-plane outer products on the matrix cores, accumulators in registers
+//   mfma (spread_mfma.hip)  default: per-plane outer products on the matrix cores, accumulators in registers
+//                           (grids of 64^3 and up, m <= 7; everything else takes the lds kernel)
+//   lds  (spread.hip)       ds_add_f64 into LDS-resident planes (also all 1-D / 2-D problems)
 //   reg  (spread_reg.hip)   atomics-free register tiles, bitwise reproducible
 // The choice fixes the pencil tiling and the order of the point plan, so it cannot change between calls.
 enum SpreadMode { kSpreadLds = 0, kSpreadMfma = 1, kSpreadReg = 2 };
