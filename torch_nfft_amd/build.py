@@ -15,7 +15,7 @@ OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libnfft_hip.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
-SOURCES = ["api.hip", "binning.hip", "spread.hip", "spread_reg.hip", "spread_mfma.hip", "interp.hip", "spectral.hip", "colfft.hip", "coeffs.hip", "fft.cpp"]
+SOURCES = ["api.hip", "binning.hip", "spread.hip", "spread_reg.hip", "spread_mfma.hip", "interp.hip", "interp_mfma.hip", "spectral.hip", "colfft.hip", "coeffs.hip", "fft.cpp"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast", "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROCM, "include")]
 

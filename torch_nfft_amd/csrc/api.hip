@@ -62,6 +62,18 @@ SpreadMode spread_mode()
 
 namespace {
 
+// interpolation: matrix-core kernel for the wide 3-D tiling unless NFFT_HIP_GATHER=lds
+int gather_any(const Geom &g, const PlanLayout &L, const void *plan, const float *grid, int64_t n, int64_t Cr,
+               int64_t plane0, int64_t nplanes, float *yr, hipStream_t s)
+{
+    static const bool lds_only = [] {
+        const char *env = std::getenv("NFFT_HIP_GATHER");
+        return env && env[0] == 'l';
+    }();
+    if (!lds_only && interp_mfma_supported(g)) return launch_interp_mfma(g, L, plan, grid, n, Cr, plane0, nplanes, yr, s);
+    return launch_interp(g, L, plan, grid, n, Cr, plane0, nplanes, yr, s);
+}
+
 int validate(const nfft_hip_problem *p)
 {
     if (!p) { set_error("Input mismatch: null problem"); return NFFT_HIP_EINVAL; }
@@ -260,7 +272,7 @@ int nfft_hip_interpolate(const nfft_hip_problem *p, const void *plan, const floa
     const PlanLayout L = plan_layout(g, p->num_points, p->batch_size);
     const int64_t planes = p->batch_size * real_columns;
     if (planes > 32768) { set_error("Input mismatch: too many planes for one interpolate call"); return NFFT_HIP_EINVAL; }
-    return launch_interp(g, L, plan, grid, p->num_points, real_columns, 0, planes, yr, (hipStream_t)stream);
+    return gather_any(g, L, plan, grid, p->num_points, real_columns, 0, planes, yr, (hipStream_t)stream);
 }
 
 static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64_t *batch, const void *ext_plan,
@@ -335,7 +347,7 @@ static int forward_impl(const nfft_hip_problem *p, const float *pos, const int64
             { StageTimer t(kStageDeconv, s); if (int rc = launch_deconv_forward(c.g, xhat, c.C, x_is_complex, real_output, p0, np, spec, s)) return rc; }
             { StageTimer t(kStageFft, s); if (int rc = fft_execute(kC2R, c.g.dim, c.g.M, np, spec, grid, work, c.work_bytes, s)) return rc; }
         }
-        { StageTimer t(kStageInterp, s); if (int rc = launch_interp(c.g, c.L, plan, grid, c.n, c.Cr, p0, np, (float *)y, s)) return rc; }
+        { StageTimer t(kStageInterp, s); if (int rc = gather_any(c.g, c.L, plan, grid, c.n, c.Cr, p0, np, (float *)y, s)) return rc; }
     }
     return 0;
 }

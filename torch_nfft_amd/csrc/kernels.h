@@ -30,6 +30,11 @@ int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, con
 // interp.hip: yr[perm[slot] * Cr + cr] = sum over taps of grid[p, ...]
 int launch_interp(const Geom &g, const PlanLayout &L, const void *plan, const float *grid, int64_t n, int64_t Cr,
                   int64_t plane0, int64_t nplanes, float *yr, hipStream_t stream);
+// matrix-core gather for the wide 3-D tiling (interp_mfma.hip); NFFT_HIP_GATHER=lds keeps launch_interp
+bool interp_mfma_supported(const Geom &g);
+int launch_interp_mfma(const Geom &g, const PlanLayout &L, const void *plan, const float *grid, int64_t n, int64_t Cr,
+                       int64_t plane0, int64_t nplanes, float *yr, hipStream_t stream);
+
 
 // spectral.hip
 // adjoint roll-off: spec = R2C(grid) per real plane [nplanes, M^(d-1) * (M/2+1)] complex -> y [B, N^d, C]

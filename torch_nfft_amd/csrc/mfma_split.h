@@ -1,0 +1,42 @@
+// Shared pieces of the matrix-core kernels (spread_mfma.hip, interp_mfma.hip): fp32 values enter
+// v_mfma_f32_32x32x16_f16 as two-way f16 splits (v = hi + lo); hi*hi + hi*lo + lo*hi keeps ~22 bits.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nfft {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Operands are scaled to at most 2^11 before the split (values <= 2048 fit f16): the lo parts, ~2^-11 of the
+// value, are then normal f16 numbers instead of subnormals; the consumer multiplies by 2^-11 per operand.
+constexpr float kOpScale = 2048.0f;
+
+// Two-way f16 split of fp32 values in three VALU instructions per pair: hi = RN16(RN32(v)), lo = RN16(v - hi) with
+// the subtraction done by the mixed-precision FMA against the hi that is actually used (letting the compiler fuse
+// the residual under -ffp-contract=fast pairs it with a differently rounded hi: one f16 ulp off near ties).
+__device__ __forceinline__ void split_pair(const float v0, const float v1, unsigned &hi, unsigned &lo)
+{
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(hi), "=&v"(lo)
+        : "v"(v0), "v"(v1));
+}
+
+// The same for products p * a: hi = RN16(p a), lo = RN16(p a - hi), both from the exact product (4 instructions).
+__device__ __forceinline__ void split_product_pair(const float p0, const float a0, const float p1, const float a1,
+                                                   unsigned &hi, unsigned &lo)
+{
+    asm("v_fma_mixlo_f16 %0, %2, %3, 0\n\t"
+        "v_fma_mixhi_f16 %0, %4, %5, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %3, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %4, %5, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(hi), "=&v"(lo)
+        : "v"(p0), "v"(a0), "v"(p1), "v"(a1));
+}
+
+
+} // namespace nfft

@@ -21,23 +21,17 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "mfma_split.h"
 
 namespace nfft {
 
 namespace {
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kKB = 16;        // points per K-block (the MFMA K dimension)
 constexpr int kNKB = 8;        // K-blocks per batch
 constexpr int kSlots = kKB * kNKB;
 constexpr int kMfmaThreads = 1024;
 constexpr int kMaxSegSlabs = 128;
-// Both operands are scaled by 2^11 before the f16 split (values <= 2048 fit f16): the lo parts, ~2^-11 of the
-// value, are then normal f16 numbers instead of subnormals; the flush multiplies by 2^-22.
-constexpr float kOpScale = 2048.0f;
 constexpr int kPsiStride = 20; // floats per row of the psi1 table (16 + 4: conflict-free ds_read_b128 over rows)
 
 // Operands of one batch of K-blocks, double-buffered: while the waves run the MFMAs of batch i they already build
@@ -49,33 +43,6 @@ struct __align__(16) MfmaOps {
     float atab[kNKB][W][kKB];             // [K-block][axis-0 tap][point]   x' * psi0
     int slab[kNKB];
 };
-
-// Points of one batch (cell fractions, in-pencil cells, scaled value), double-buffered as well.
-// Two-way f16 split of fp32 values in three VALU instructions per pair: hi = RN16(RN32(v)), lo = RN16(v - hi) with
-// the subtraction done by the mixed-precision FMA against the hi that is actually used (letting the compiler fuse
-// the residual under -ffp-contract=fast pairs it with a differently rounded hi: one f16 ulp off near ties).
-__device__ __forceinline__ void split_pair(const float v0, const float v1, unsigned &hi, unsigned &lo)
-{
-    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
-        "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(hi), "=&v"(lo)
-        : "v"(v0), "v"(v1));
-}
-
-// The same for products p * a: hi = RN16(p a), lo = RN16(p a - hi), both from the exact product (4 instructions).
-__device__ __forceinline__ void split_product_pair(const float p0, const float a0, const float p1, const float a1,
-                                                   unsigned &hi, unsigned &lo)
-{
-    asm("v_fma_mixlo_f16 %0, %2, %3, 0\n\t"
-        "v_fma_mixhi_f16 %0, %4, %5, 0\n\t"
-        "v_fma_mixlo_f16 %1, %2, %3, -%0 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %1, %4, %5, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(hi), "=&v"(lo)
-        : "v"(p0), "v"(a0), "v"(p1), "v"(a1));
-}
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // One dword per active lane, global -> LDS without a register in between (LDS-DMA): lane l of the wave lands at
 // lds_wave_base + 4 l.  Issued through asm so that the compiler does not drain it (vmcnt(0)) at the next LDS read or
@@ -94,6 +61,7 @@ __device__ __forceinline__ void wait_lds_dma() { asm volatile("s_waitcnt vmcnt(0
 // workgroup barrier that leaves global traffic (LDS-DMA, flush atomics) in flight
 __device__ __forceinline__ void barrier_lds_only() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Points of one batch (cell fractions, in-pencil cells, scaled value), double-buffered as well.
 struct __align__(16) MfmaStage {
     float f0[kSlots], f1[kSlots], f2[kSlots], x[kSlots];
     int c1[kSlots], c2[kSlots];
@@ -168,13 +136,14 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     auto flush = [&]() {
         if (dirty) {
             const int gz = wrap(myz, g.M);
+            const float zscale = ((myz + m) & 1) ? -unscale : unscale;  // plane s - m + l0: parity of s + l0 + m
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int gc = wrap_near(tb2 - m + 32 * t + r32, g.M);
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    const float v = (t == 0 ? acc0[reg] : acc1[reg]) * unscale;
+                    const float v = (t == 0 ? acc0[reg] : acc1[reg]) * zscale;
                     if (v != 0.0f) {
                         const int gr = wrap_near(tb1 - m + row, g.M);
                         atomicAdd(gplane + ((int64_t)gz * g.M + gr) * g.M + gc, v);
@@ -315,7 +284,10 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                     const int l0 = e / kKB, k = e - l0 * kKB;
                     const int slot = j * kKB + k;
                     const float d = S.f0[slot] + (float)(m - l0);
-                    O.atab[j][l0][k] = S.x[slot] * __builtin_amdgcn_exp2f(sc * d * d) * kOpScale;
+                    // odd planes accumulate the negated sum (undone at the flush): the sign-independent part of the
+                    // MFMA accumulation's truncation bias then alternates from plane to plane
+                    const float sgn = ((S.slab[j] + l0) & 1) ? -kOpScale : kOpScale;
+                    O.atab[j][l0][k] = S.x[slot] * __builtin_amdgcn_exp2f(sc * d * d) * sgn;
                 }
                 if (lane == 0) O.slab[j] = S.slab[j];
             }
