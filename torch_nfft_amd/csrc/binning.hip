@@ -19,7 +19,7 @@ PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)
 {
     PlanLayout L;
     L.ntiles = (int64_t)g.tiles_per_batch * B * g.SB;  // (tile, sub-block) bins
-    L.npencils = (int64_t)g.nta[1] * g.nta[2] * B;
+    L.npencils = (int64_t)g.nta[1] * g.nta[2] * B * g.l1seg;  // first-level bins: (batch, pencil, segment)
     L.nblocks = (n + kSortBlockPoints - 1) / kSortBlockPoints;
     L.two_level = L.npencils <= kMaxPencilsLds && L.npencils * L.nblocks < (int64_t(1) << 28) && n > 0;
     const int64_t scan_items = L.two_level ? L.npencils * L.nblocks + 1 : L.ntiles + 1;
@@ -89,9 +89,11 @@ __device__ __forceinline__ void point_cells(const Geom &g, const float *__restri
     }
 }
 
+// first-level bin: (batch, pencil, segment of l1bins plan bins along axis 0)
 __device__ __forceinline__ int pencil_of(const Geom &g, const int cell[3], int64_t b)
 {
-    return ((int)b * g.nta[1] + cell[1] / g.Ta[1]) * g.nta[2] + cell[2] / g.Ta[2];
+    const int pencil = ((int)b * g.nta[1] + cell[1] / g.Ta[1]) * g.nta[2] + cell[2] / g.Ta[2];
+    return g.l1seg == 1 ? pencil : pencil * g.l1seg + (cell[0] / g.bin0) / g.l1bins;
 }
 
 __global__ void __launch_bounds__(kSortThreads)
@@ -138,14 +140,14 @@ sort1_scatter_kernel(Geom g, const float *__restrict__ pos, const int64_t *__res
     }
 }
 
-// (chunk, sub-block) key of a level-1 record inside its pencil
-__device__ __forceinline__ int fine_key(const Geom &g, const float4 rec)
+// (axis-0 bin, sub-block) key of a level-1 record inside its first-level bin (whose first axis-0 bin is bin_lo)
+__device__ __forceinline__ int fine_key(const Geom &g, const float4 rec, const int bin_lo)
 {
     if (g.dim != 3) return 0;
     int cell[3];
     float fr;
     split_cell(rec.x, g.M, cell[0], fr);
-    int key = cell[0] / g.bin0;
+    int key = cell[0] / g.bin0 - bin_lo;
     if (g.SB > 1) {
         split_cell(rec.y, g.M, cell[1], fr);
         split_cell(rec.z, g.M, cell[2], fr);
@@ -159,14 +161,17 @@ sort2_kernel(Geom g, int64_t n, int npencils, int nblocks, const int *__restrict
              const float4 *__restrict__ tmp, int *__restrict__ offsets, int *__restrict__ perm,
              float *__restrict__ spos)
 {
-    extern __shared__ int lds2[];  // [nt0 * SB] counts -> cursors
-    const int pencil = blockIdx.x;
-    const int nt0 = g.np0 * g.SB;  // (axis-0 bin, sub-block) bins of this pencil
-    const int p0 = hscan[(int64_t)pencil * nblocks];
-    const int p1 = pencil + 1 < npencils ? hscan[(int64_t)(pencil + 1) * nblocks] : (int)n;
+    extern __shared__ int lds2[];  // [bins of this first-level bin * SB] counts -> cursors
+    const int l1 = blockIdx.x;
+    const int pencil = l1 / g.l1seg, sg = l1 - pencil * g.l1seg;
+    const int bin_lo = sg * g.l1bins;
+    const int nt0 = (min(g.np0, bin_lo + g.l1bins) - bin_lo) * g.SB;  // (axis-0 bin, sub-block) bins handled here
+    const int64_t obase = ((int64_t)pencil * g.np0 + bin_lo) * g.SB;   // their first entry in the offsets table
+    const int p0 = hscan[(int64_t)l1 * nblocks];
+    const int p1 = l1 + 1 < npencils ? hscan[(int64_t)(l1 + 1) * nblocks] : (int)n;
     for (int i = threadIdx.x; i < nt0; i += kSortThreads) lds2[i] = 0;
     __syncthreads();
-    for (int j = p0 + threadIdx.x; j < p1; j += kSortThreads) atomicAdd(&lds2[fine_key(g, tmp[j])], 1);
+    for (int j = p0 + threadIdx.x; j < p1; j += kSortThreads) atomicAdd(&lds2[fine_key(g, tmp[j], bin_lo)], 1);
     __syncthreads();
     // exclusive scan of the nt0 chunk counts by one wave (nt0 is small: M / TC)
     if (threadIdx.x < 64) {
@@ -182,16 +187,16 @@ sort2_kernel(Geom g, int64_t n, int npencils, int nblocks, const int *__restrict
             if (idx < nt0) {
                 const int excl = carry + incl - v;
                 lds2[idx] = excl;                      // cursor of chunk idx (relative to p0)
-                offsets[(int64_t)pencil * nt0 + idx] = p0 + excl;
+                offsets[obase + idx] = p0 + excl;
             }
             carry += __shfl(incl, 63);
         }
-        if (pencil == npencils - 1 && threadIdx.x == 0) offsets[(int64_t)npencils * nt0] = (int)n;
+        if (l1 == npencils - 1 && threadIdx.x == 0) offsets[obase + nt0] = (int)n;
     }
     __syncthreads();
     for (int j = p0 + threadIdx.x; j < p1; j += kSortThreads) {
         const float4 rec = tmp[j];
-        const int slot = p0 + atomicAdd(&lds2[fine_key(g, rec)], 1);
+        const int slot = p0 + atomicAdd(&lds2[fine_key(g, rec, bin_lo)], 1);
         perm[slot] = __float_as_int(rec.w);
         spos[(int64_t)slot * g.dim] = rec.x;
         if (g.dim > 1) spos[(int64_t)slot * g.dim + 1] = rec.y;
@@ -257,7 +262,7 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
         NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(base + L.off_scan, scan_bytes, hist, hscan, (int)items, stream));
         hipLaunchKernelGGL(sort1_scatter_kernel, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
                            npencils, nblocks, hscan, tmp);
-        hipLaunchKernelGGL(sort2_kernel, dim3(npencils), dim3(kSortThreads), (size_t)g.np0 * g.SB * 4, stream, g, n,
+        hipLaunchKernelGGL(sort2_kernel, dim3(npencils), dim3(kSortThreads), (size_t)g.l1bins * g.SB * 4, stream, g, n,
                            npencils, nblocks, hscan, tmp, offsets, perm, spos);
         NFFT_HIP_CHECK(hipGetLastError());
         return 0;

@@ -74,6 +74,8 @@ struct Geom {
     int bin0;     // planes per plan bin along axis 0: Ta[0], or 1 for the wide tiling
     int np0;      // plan bins per pencil along axis 0
     int tiles_per_batch;  // plan bins per point set: np0 * nta[1] * nta[2]
+    int l1seg;    // first-level sort bins per pencil (segments along axis 0)
+    int l1bins;   // plan bins along axis 0 per first-level segment
     // Every tile is further split into sb1 x sb2 sub-blocks of kSub x kSub cells in (axis 1, axis 2); the point
     // plan is sorted down to (tile, sub-block), so a tile's points are contiguous AND grouped by sub-block.
     // tile_offsets has one entry per (tile, sub-block): index tile * SB + s1 * sb2 + s2.
@@ -110,6 +112,9 @@ inline Geom make_geom(int dim, int64_t N, int64_t m)
     g.bin0 = g.wide ? 1 : g.Ta[0];
     g.np0 = g.wide ? g.Ma[0] : g.nta[0];
     g.tiles_per_batch = g.np0 * g.nta[1] * g.nta[2];
+    // the wide tiling has few, long pencils: its second-level sort works on segments of 128 slabs
+    g.l1bins = g.wide ? 128 : g.np0;
+    g.l1seg = (g.np0 + g.l1bins - 1) / g.l1bins;
     // only the opt-in register-tile spreading kernel needs the sub-block order (it costs ~0.25 ms of sorting at C3)
     const bool sub = subblock_plan_enabled() && dim == 3 && g.M % kSub == 0 && g.Ta[1] % kSub == 0 &&
                      g.Ta[2] % kSub == 0;
