@@ -58,6 +58,15 @@ def test_config_c2_2d_n128_m4_100k(tn):
     assert errf < T2_M4
 
 
+def test_grid_1024_cubed(tn):
+    """N = 512 (oversampled grid 1024^3, the largest size of the fused column passes: radix sequence 8, 8, 4, 4)."""
+    pos, x, y, err = _subset_check_adjoint(tn, 3, 512, 4, 200_000, 48, 9)
+    assert y.shape == (1, 512, 512, 512) and err < T2_M4
+    del y
+    _, yf, errf = _sparse_forward_check(tn, pos, 512, 4, 8, 10)
+    assert errf < T2_M4
+
+
 def test_config_c3_3d_n256_m4_10m(tn):
     n, N, m = 10_000_000, 256, 4
     pos, x, y, err = _subset_check_adjoint(tn, 3, N, m, n, 48, 4)

@@ -130,6 +130,20 @@ def test_adjoint_and_forward_vs_oracle(tn, d, N, m, complex_x):
     assert rel_l2(host(yf), ndft.ndft_forward(xh, pos, batch)) < T2[m]
 
 
+@pytest.mark.parametrize("N,m", [(8, 2), (64, 4), (64, 2)])
+def test_column_fft_sizes_3d(tn, N, m):
+    """Grids of 16^3 and 128^3 exercise the radix sequences (4,4) and (8,4,4) of the fused column passes (the other
+    tests cover 32, 64, 256 and 512; 1024 is in test_gpu_large.py); 128^3 also takes the matrix-core kernels."""
+    rng = np.random.default_rng(300 + N + m)
+    n = 3000
+    pos, batch, x = _random_problem(rng, 3, n, 1, (), True)
+    ya = tn.nfft_adjoint(dev(x), dev(pos), None, bandwidth=N, cutoff=m)
+    assert rel_l2(host(ya), nfft_ref.nfft_adjoint(x, pos, None, N=N, m=m)) < T1
+    xh = (rng.standard_normal((1, N, N, N)) + 1j * rng.standard_normal((1, N, N, N))).astype(np.complex64)
+    yf = tn.nfft_forward(dev(xh), dev(pos), None, cutoff=m)
+    assert rel_l2(host(yf), nfft_ref.nfft_forward(xh, pos, None, m=m)) < T1
+
+
 @pytest.mark.parametrize("d", [1, 2, 3])
 def test_real_output_variants(tn, d):
     rng = np.random.default_rng(77 + d)

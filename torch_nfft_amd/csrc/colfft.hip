@@ -10,7 +10,7 @@
 //
 // which cuts their HBM traffic to a quarter / an eighth of the full passes and removes the separate
 // roll-off kernels (adjoint) and the zero-fill of the padded spectrum (forward).  One workgroup transforms
-// a tile of NC adjacent k2-columns entirely in LDS (radix-2 DIF, bit-reversed output addressing), so
+// a tile of NC adjacent k2-columns entirely in LDS (radix-8/4 DIF, digit-reversed output addressing), so
 // every global access is a run of NC * 8 contiguous bytes.
 //
 // "band+" is k in [-N/2, N/2]: the extra +N/2 row feeds the Hermitian mirror g_hat[-k] = conj(g_hat[k])
@@ -51,33 +51,129 @@ __global__ void twiddle_kernel(float2 *tw, int M)
     }
 }
 
-// In-place radix-2 decimation-in-frequency FFT along the row index of buf[M][NC]; X[k] ends up in row brev(k).
-// INV selects exp(+2 pi i ...).  ltw is the twiddle table staged in LDS.
+// In-place decimation-in-frequency FFT along the row index of buf[M][NC], radix 8 / 4 stages with the butterflies in
+// registers: a radix-R step on blocks of length L reads x_q = buf[base + j + q L/R], forms y_p = (sum_q x_q W_R^{pq})
+// W_L^{jp} and stores y_p back to buf[base + p L/R + j]; sub-block p then holds the transform of the outputs
+// k = p (mod R).  X[k] ends up in row out_row(k) (mixed-radix digit reversal).  M = 512 takes 3 LDS round trips
+// (8 x 8 x 8) instead of the 9 of a radix-2 pass.  INV selects exp(+2 pi i ...).  ltw = exp(-2 pi i j / M), j < M/2.
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// multiply by -i (forward) / +i (inverse)
+template <bool INV>
+__device__ __forceinline__ float2 rot90(float2 a)
+{
+    return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft4(float2 &x0, float2 &x1, float2 &x2, float2 &x3)
+{
+    const float2 a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), a3 = rot90<INV>(csub(x1, x3));
+    x0 = cadd(a0, a2);
+    x1 = cadd(a1, a3);
+    x2 = csub(a0, a2);
+    x3 = csub(a1, a3);
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft8(float2 (&x)[8])
+{
+    // even / odd radix-4 transforms, then y[p] = E[p] + W8^p O[p], y[p + 4] = E[p] - W8^p O[p]
+    dft4<INV>(x[0], x[2], x[4], x[6]);
+    dft4<INV>(x[1], x[3], x[5], x[7]);
+    constexpr float r = 0.70710678118654752440f;
+    const float2 o0 = x[1];
+    const float2 o1 = INV ? make_float2((x[3].x - x[3].y) * r, (x[3].x + x[3].y) * r)
+                          : make_float2((x[3].x + x[3].y) * r, (x[3].y - x[3].x) * r);
+    const float2 o2 = rot90<INV>(x[5]);
+    const float2 o3 = INV ? make_float2((-x[7].x - x[7].y) * r, (x[7].x - x[7].y) * r)
+                          : make_float2((x[7].y - x[7].x) * r, (-x[7].x - x[7].y) * r);
+    const float2 e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6];
+    x[0] = cadd(e0, o0); x[4] = csub(e0, o0);
+    x[1] = cadd(e1, o1); x[5] = csub(e1, o1);
+    x[2] = cadd(e2, o2); x[6] = csub(e2, o2);
+    x[3] = cadd(e3, o3); x[7] = csub(e3, o3);
+}
+
+template <bool INV>
+__device__ __forceinline__ float2 twiddle_at(const float2 *ltw, int e, int M)
+{
+    e &= M - 1;
+    float2 w = ltw[e & (M / 2 - 1)];
+    if (e >= M / 2) w = make_float2(-w.x, -w.y);
+    if (INV) w.y = -w.y;
+    return w;
+}
+
+template <bool INV, int R>
+__device__ __forceinline__ void fft_stage(float2 *buf, const float2 *ltw, const ColGeom &cg, int tid, int logL)
+{
+    constexpr int logR = R == 8 ? 3 : 2;
+    const int logLs = logL - logR, Ls = 1 << logLs;
+    const int tstep = cg.M >> logL;
+    const int total = (cg.M >> logR) << cg.logNC;
+    __syncthreads();
+    for (int idx = tid; idx < total; idx += kFftThreads) {
+        const int col = idx & (cg.NC - 1);
+        const int t = idx >> cg.logNC;
+        const int j = t & (Ls - 1);
+        const int row0 = ((t >> logLs) << logL) + j;
+        float2 *p0 = buf + (row0 << cg.logNC) + col;
+        const int stride = Ls << cg.logNC;
+        float2 x[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) x[q] = p0[q * stride];
+        if (R == 8) {
+            dft8<INV>(reinterpret_cast<float2(&)[8]>(x));
+        } else {
+            dft4<INV>(x[0], x[1], x[2], x[3]);
+        }
+        p0[0] = x[0];
+        if (logLs == 0) {
+#pragma unroll
+            for (int q = 1; q < R; ++q) p0[q * stride] = x[q];
+        } else {
+#pragma unroll
+            for (int q = 1; q < R; ++q) p0[q * stride] = cmul(x[q], twiddle_at<INV>(ltw, j * q * tstep, cg.M));
+        }
+    }
+}
+
 template <bool INV>
 __device__ __forceinline__ void lds_fft(float2 *buf, const float2 *ltw, const ColGeom &cg, int tid)
 {
-    const int total = (cg.M / 2) << cg.logNC;
-    int shift = 0;
-    for (int h = cg.M / 2; h >= 1; h >>= 1, ++shift) {
-        __syncthreads();
-        for (int idx = tid; idx < total; idx += kFftThreads) {
-            const int col = idx & (cg.NC - 1);
-            const int t = idx >> cg.logNC;
-            const int j = t & (h - 1);
-            const int i = ((t - j) << 1) + j;
-            float2 *pa = buf + (i << cg.logNC) + col;
-            float2 *pb = buf + ((i + h) << cg.logNC) + col;
-            const float2 a = *pa, b = *pb;
-            float2 w = ltw[j << shift];
-            if (INV) w.y = -w.y;
-            *pa = make_float2(a.x + b.x, a.y + b.y);
-            *pb = cmul(make_float2(a.x - b.x, a.y - b.y), w);
-        }
+    switch (cg.logM) {
+    case 4: fft_stage<INV, 4>(buf, ltw, cg, tid, 4); fft_stage<INV, 4>(buf, ltw, cg, tid, 2); break;
+    case 5: fft_stage<INV, 8>(buf, ltw, cg, tid, 5); fft_stage<INV, 4>(buf, ltw, cg, tid, 2); break;
+    case 6: fft_stage<INV, 8>(buf, ltw, cg, tid, 6); fft_stage<INV, 8>(buf, ltw, cg, tid, 3); break;
+    case 7: fft_stage<INV, 8>(buf, ltw, cg, tid, 7); fft_stage<INV, 4>(buf, ltw, cg, tid, 4);
+            fft_stage<INV, 4>(buf, ltw, cg, tid, 2); break;
+    case 8: fft_stage<INV, 8>(buf, ltw, cg, tid, 8); fft_stage<INV, 8>(buf, ltw, cg, tid, 5);
+            fft_stage<INV, 4>(buf, ltw, cg, tid, 2); break;
+    case 9: fft_stage<INV, 8>(buf, ltw, cg, tid, 9); fft_stage<INV, 8>(buf, ltw, cg, tid, 6);
+            fft_stage<INV, 8>(buf, ltw, cg, tid, 3); break;
+    default: fft_stage<INV, 8>(buf, ltw, cg, tid, 10); fft_stage<INV, 8>(buf, ltw, cg, tid, 7);
+             fft_stage<INV, 4>(buf, ltw, cg, tid, 4); fft_stage<INV, 4>(buf, ltw, cg, tid, 2); break;
     }
     __syncthreads();
 }
 
-__device__ __forceinline__ int brev_row(int k, int logM) { return (int)(__brev((unsigned)k) >> (32 - logM)); }
+// Row that holds X[k] after lds_fft: the digits of k in the radix sequence above, most significant first.
+__device__ __forceinline__ int brev_row(int k, int logM)
+{
+    int pos = 0, lg = logM;
+    auto digit = [&](int lr) { lg -= lr; pos += (k & ((1 << lr) - 1)) << lg; k >>= lr; };
+    switch (logM) {
+    case 4: digit(2); digit(2); break;
+    case 5: digit(3); digit(2); break;
+    case 6: digit(3); digit(3); break;
+    case 7: digit(3); digit(2); digit(2); break;
+    case 8: digit(3); digit(3); digit(2); break;
+    case 9: digit(3); digit(3); digit(3); break;
+    default: digit(3); digit(3); digit(2); digit(2); break;
+    }
+    return pos;
+}
 
 __device__ __forceinline__ void stage_twiddles(float2 *ltw, const float2 *__restrict__ tw, int M, int tid)
 {
