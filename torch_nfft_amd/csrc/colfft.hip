@@ -175,6 +175,26 @@ __device__ __forceinline__ int brev_row(int k, int logM)
     return pos;
 }
 
+// Fills LDS from global memory with UN loads per thread in flight before the first one is consumed: a tile has to
+// keep ~64 KB outstanding per CU to cover the HBM latency (two 256-thread workgroups share a CU).
+template <int UN, typename LoadF, typename StoreF>
+__device__ __forceinline__ void batched_fill(int total, int tid, LoadF load, StoreF store)
+{
+    for (int base = tid; base < total; base += kFftThreads * UN) {
+        float2 v[UN];
+#pragma unroll
+        for (int r = 0; r < UN; ++r) {
+            const int idx = base + r * kFftThreads;
+            v[r] = idx < total ? load(idx) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int r = 0; r < UN; ++r) {
+            const int idx = base + r * kFftThreads;
+            if (idx < total) store(idx, v[r]);
+        }
+    }
+}
+
 __device__ __forceinline__ void stage_twiddles(float2 *ltw, const float2 *__restrict__ tw, int M, int tid)
 {
     for (int j = tid; j < M / 2; j += kFftThreads) ltw[j] = tw[j];
@@ -193,11 +213,13 @@ adj_axis1_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__rest
     const int64_t plane = blockIdx.z;
     stage_twiddles(ltw, tw, cg.M, tid);
     const float2 *src = S + ((plane * cg.M + u0) * cg.M) * cg.Mh;
-    for (int idx = tid; idx < (cg.M << cg.logNC); idx += kFftThreads) {
-        const int col = idx & (cg.NC - 1), u1 = idx >> cg.logNC;
-        const int k2 = c0 + col;
-        buf[idx] = k2 < cg.KC ? src[(int64_t)u1 * cg.Mh + k2] : make_float2(0.f, 0.f);
-    }
+    batched_fill<16>(cg.M << cg.logNC, tid,
+                     [&](int idx) {
+                         const int col = idx & (cg.NC - 1), u1 = idx >> cg.logNC;
+                         const int k2 = c0 + col;
+                         return k2 < cg.KC ? src[(int64_t)u1 * cg.Mh + k2] : make_float2(0.f, 0.f);
+                     },
+                     [&](int idx, float2 v) { buf[idx] = v; });
     lds_fft<false>(buf, ltw, cg, tid);
     float2 *dst = T + ((plane * cg.M + u0) * cg.NB) * cg.KC;
     for (int idx = tid; idx < (cg.NB << cg.logNC); idx += kFftThreads) {
@@ -230,12 +252,16 @@ adj_axis0_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__rest
     const int64_t plane = XCOMPLEX ? col_local * 2 : col_local;
     const int64_t pstride = (int64_t)cg.M * cg.NB * cg.KC;
     const float2 *src = T + plane * pstride + (int64_t)j1 * cg.KC;
-    for (int idx = tid; idx < (cg.M << cg.logNC); idx += kFftThreads) {
-        const int col = idx & (cg.NC - 1), u0 = idx >> cg.logNC;
-        const int k2 = c0 + col;
-        const int64_t off = (int64_t)u0 * cg.NB * cg.KC + k2;
-        buf[idx] = k2 < cg.KC ? src[off] : make_float2(0.f, 0.f);
-        if (XCOMPLEX) buf2[idx] = k2 < cg.KC ? src[pstride + off] : make_float2(0.f, 0.f);
+    for (int part = 0; part < (XCOMPLEX ? 2 : 1); ++part) {
+        float2 *const dstbuf = part ? buf2 : buf;
+        const float2 *const srcp = src + part * pstride;
+        batched_fill<16>(cg.M << cg.logNC, tid,
+                         [&](int idx) {
+                             const int col = idx & (cg.NC - 1), u0 = idx >> cg.logNC;
+                             const int k2 = c0 + col;
+                             return k2 < cg.KC ? srcp[(int64_t)u0 * cg.NB * cg.KC + k2] : make_float2(0.f, 0.f);
+                         },
+                         [&](int idx, float2 v) { dstbuf[idx] = v; });
     }
     lds_fft<false>(buf, ltw, cg, tid);
     if (XCOMPLEX) lds_fft<false>(buf2, ltw, cg, tid);
@@ -307,19 +333,22 @@ fwd_axis0_kernel(ColGeom cg, const float2 *__restrict__ tw, const void *__restri
     const int H = cg.H;
     const int k1 = j1 - H;
     const float f1 = phi_hat_inv_f(abs(k1), cg.param);
-    for (int idx = tid; idx < (cg.NB << cg.logNC); idx += kFftThreads) {
-        const int col = idx & (cg.NC - 1), j0 = idx >> cg.logNC;
-        const int k2 = c0 + col;
-        if (k2 >= cg.KC) continue;
-        const int k0 = j0 - H;
-        const float2 ap = band_value<XCOMPLEX>(xhat, b, c, C, cg.N, H, k0, k1, k2);
-        const float2 am = band_value<XCOMPLEX>(xhat, b, c, C, cg.N, H, -k0, -k1, -k2);
-        const float fac = 0.5f * phi_hat_inv_f(abs(k0), cg.param) * f1 * phi_hat_inv_f(k2, cg.param);
-        float2 v;
-        if (part == 0) v = make_float2((am.x + ap.x) * fac, (am.y - ap.y) * fac);
-        else v = make_float2((am.y + ap.y) * fac, -(am.x - ap.x) * fac);
-        buf[((k0 & (cg.M - 1)) << cg.logNC) + col] = v;
-    }
+    batched_fill<8>(cg.NB << cg.logNC, tid,
+                    [&](int idx) {
+                        const int col = idx & (cg.NC - 1), j0 = idx >> cg.logNC;
+                        const int k2 = c0 + col;
+                        if (k2 >= cg.KC) return make_float2(0.f, 0.f);
+                        const int k0 = j0 - H;
+                        const float2 ap = band_value<XCOMPLEX>(xhat, b, c, C, cg.N, H, k0, k1, k2);
+                        const float2 am = band_value<XCOMPLEX>(xhat, b, c, C, cg.N, H, -k0, -k1, -k2);
+                        const float fac = 0.5f * phi_hat_inv_f(abs(k0), cg.param) * f1 * phi_hat_inv_f(k2, cg.param);
+                        if (part == 0) return make_float2((am.x + ap.x) * fac, (am.y - ap.y) * fac);
+                        return make_float2((am.y + ap.y) * fac, -(am.x - ap.x) * fac);
+                    },
+                    [&](int idx, float2 v) {
+                        const int col = idx & (cg.NC - 1), j0 = idx >> cg.logNC;
+                        if (c0 + col < cg.KC) buf[(((j0 - H) & (cg.M - 1)) << cg.logNC) + col] = v;
+                    });
     lds_fft<true>(buf, ltw, cg, tid);
     float2 *dst = T + pl * ((int64_t)cg.M * cg.NB * cg.KC) + (int64_t)j1 * cg.KC;
     for (int idx = tid; idx < (cg.M << cg.logNC); idx += kFftThreads) {
@@ -352,11 +381,16 @@ fwd_axis1_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__rest
     for (int idx = tid; idx < (cg.M << cg.logNC); idx += kFftThreads) buf[idx] = make_float2(0.f, 0.f);
     __syncthreads();
     const float2 *src = T + ((plane * cg.M + u0) * cg.NB) * cg.KC;
-    for (int idx = tid; idx < (cg.NB << cg.logNC); idx += kFftThreads) {
-        const int col = idx & (cg.NC - 1), j1 = idx >> cg.logNC;
-        const int k2 = c0 + col;
-        if (k2 < cg.KC) buf[(((j1 - cg.H) & (cg.M - 1)) << cg.logNC) + col] = src[(int64_t)j1 * cg.KC + k2];
-    }
+    batched_fill<16>(cg.NB << cg.logNC, tid,
+                     [&](int idx) {
+                         const int col = idx & (cg.NC - 1), j1 = idx >> cg.logNC;
+                         const int k2 = c0 + col;
+                         return k2 < cg.KC ? src[(int64_t)j1 * cg.KC + k2] : make_float2(0.f, 0.f);
+                     },
+                     [&](int idx, float2 v) {
+                         const int col = idx & (cg.NC - 1), j1 = idx >> cg.logNC;
+                         if (c0 + col < cg.KC) buf[(((j1 - cg.H) & (cg.M - 1)) << cg.logNC) + col] = v;
+                     });
     lds_fft<true>(buf, ltw, cg, tid);
     for (int idx = tid; idx < (cg.M << cg.logNC); idx += kFftThreads) {
         const int col = idx & (cg.NC - 1), u1 = idx >> cg.logNC;
