@@ -46,7 +46,7 @@ interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: keep it in an SGPR
     const int r32 = lane & 31, h = lane >> 5;
 
     const int seg = blockIdx.x % g.nseg;

@@ -91,7 +91,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: keep it in an SGPR
     const int r32 = lane & 31, h = lane >> 5;
 
     const int seg = blockIdx.x % nsegm;
@@ -131,7 +131,15 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     f32x16 acc0 = 0.0f, acc1 = 0.0f;
     bool dirty = false;
     // wave w owns the plane congruent to w (mod 16) inside the sliding window that starts at sb - m
-    int myz = (sb - m) + (((wave - (sb - m)) % 16) + 16) % 16;
+    // (for 2m+2 <= 12 only 12 waves own planes: the other four -- one per SIMD -- stage points and build operands
+    // full time instead of idling through the accumulation)
+    constexpr int NOWN = W <= 12 ? 12 : 16;
+    const bool owner = wave < NOWN;
+    int myz = (sb - m) + (((wave - (sb - m)) % NOWN) + NOWN) % NOWN;
+    // staging threads: the first two non-owner waves if there are any, else waves 0 and 1
+    constexpr int kStageWave0 = NOWN == 16 ? 0 : NOWN;
+    const int st = tid - kStageWave0 * 64;  // slot of a staging thread, in [0, kSlots)
+    const bool stager = (unsigned)st < (unsigned)kSlots;
 
     auto flush = [&]() {
         if (dirty) {
@@ -182,7 +190,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     // L.raw) while batch i is accumulated, and converted to (cell, fraction) form one step later.
     int cur = 0;  // slab of this thread's previous K-block (K-blocks only move forward)
     auto stage_request = [&](const int batch) {
-        const int j = tid / kKB, i = tid - j * kKB;
+        const int j = st / kKB, i = st - j * kKB;
         const int q = batch * kNKB + j;
         int have = 0, slab = INT_MAX;
         if (q < total) {
@@ -203,31 +211,31 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
             const int idx = e0.y + kKB * (q - e0.x) + i;
             have = idx < e1.y;
             if (have) {
-                lds_dma_dword(spos + (int64_t)idx * 3 + 0, &L.raw[0][wave * 64]);
-                lds_dma_dword(spos + (int64_t)idx * 3 + 1, &L.raw[1][wave * 64]);
-                lds_dma_dword(spos + (int64_t)idx * 3 + 2, &L.raw[2][wave * 64]);
-                lds_dma_dword(xcol + idx, &L.raw[3][wave * 64]);
+                lds_dma_dword(spos + (int64_t)idx * 3 + 0, &L.raw[0][(wave - kStageWave0) * 64]);
+                lds_dma_dword(spos + (int64_t)idx * 3 + 1, &L.raw[1][(wave - kStageWave0) * 64]);
+                lds_dma_dword(spos + (int64_t)idx * 3 + 2, &L.raw[2][(wave - kStageWave0) * 64]);
+                lds_dma_dword(xcol + idx, &L.raw[3][(wave - kStageWave0) * 64]);
             }
         }
-        L.raw_have[tid] = have;
+        L.raw_have[st] = have;
         if (i == 0) L.raw_slab[j] = slab;
     };
     auto stage_convert = [&](MfmaStage &S) {
         wait_lds_dma();
         float f0 = 0.f, f1 = 0.f, f2 = 0.f, xv = 0.f;
         int c1 = -1000, c2 = -1000;  // padding slots: outside every window
-        if (L.raw_have[tid]) {
+        if (L.raw_have[st]) {
             int c0;
-            split_cell(L.raw[0][tid], g.M, c0, f0);
-            split_cell(L.raw[1][tid], g.M, c1, f1);
-            split_cell(L.raw[2][tid], g.M, c2, f2);
+            split_cell(L.raw[0][st], g.M, c0, f0);
+            split_cell(L.raw[1][st], g.M, c1, f1);
+            split_cell(L.raw[2][st], g.M, c2, f2);
             c1 -= tb1 - m;  // row of the point's cell inside the padded pencil (tap l1 sits at row c1 - m + l1)
             c2 -= tb2 - m;
-            xv = L.raw[3][tid] * inv_xscale;
+            xv = L.raw[3][st] * inv_xscale;
         }
-        S.f0[tid] = f0; S.f1[tid] = f1; S.f2[tid] = f2; S.x[tid] = xv;
-        S.c1[tid] = c1; S.c2[tid] = c2;
-        if ((tid & (kKB - 1)) == 0) S.slab[tid / kKB] = L.raw_slab[tid / kKB];  // written by this same thread
+        S.f0[st] = f0; S.f1[st] = f1; S.f2[st] = f2; S.x[st] = xv;
+        S.c1[st] = c1; S.c2[st] = c2;
+        if ((st & (kKB - 1)) == 0) S.slab[st / kKB] = L.raw_slab[st / kKB];  // written by this same thread
     };
 
     // ---- operands of a batch: three wave-sized tasks per K-block, handed out through an LDS counter so that the
@@ -302,7 +310,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
             // the sweep has passed plane myz once the current slab is beyond myz + m
             while (myz + m < s) {
                 flush();
-                myz += 16;
+                myz += NOWN;
             }
             const int l0 = myz - s + m;  // axis-0 tap of this K-block's points that lands on my plane
             if ((unsigned)l0 < (unsigned)W) {
@@ -333,19 +341,19 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     // i - 1) into staging buffer i & 1 (its last reader, build_operands of batch i in step i - 1, is behind the previous
     // barrier), request batch i + 3, build the operands of batch i + 1 (buffer (i+1) & 1) and run the MFMAs of batch i.
     if (tid < 2) L.task_counter[tid] = 0;
-    if (tid < kSlots) {
+    if (stager) {
         stage_request(0);
         stage_convert(L.stag[0]);
         if (1 < nbatch) stage_request(1);
     }
     __syncthreads();
     for (int i = -1; i < nbatch; ++i) {
-        if (tid < kSlots) {
+        if (stager) {
             if (i + 2 < nbatch) stage_convert(L.stag[i & 1]);
             if (i + 3 < nbatch) stage_request(i + 3);
         }
         if (tid == 0) L.task_counter[i & 1] = 0;  // for the next step; its last user is behind the previous barrier
-        if (i >= 0) accumulate(L.ops[i & 1], min(kNKB, total - i * kNKB));
+        if (i >= 0 && owner) accumulate(L.ops[i & 1], min(kNKB, total - i * kNKB));
         if (i + 1 < nbatch)
             build_tasks(L.stag[(i + 1) & 1], L.ops[(i + 1) & 1], min(kNKB, total - (i + 1) * kNKB),
                         &L.task_counter[(i + 1) & 1]);
