@@ -25,7 +25,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_FMA_PER_S = 78.65e12      # 157.3 TFLOP/s fp32 vector = 78.65e12 FMA/s
-LDS_ATOMIC_PER_S = 256 * 16 * 2.4e9  # ds_add_f32 at the ds_write_b32 rate: 16 lanes/clk/CU
+MFMA_F16_FLOPS = 2.5e15        # dense f16 matrix peak (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -44,9 +44,9 @@ def parse():
 
 def measured_traffic(d, N, m, n):
     """HBM bytes per launch of the spreading kernel from the committed rocprofv3 PMC passes (FETCH_SIZE with the
-    gfx950 x2 correction + WRITE_SIZE; profiles/r01_v2_spread_traffic.json), if they were taken on this workload."""
+    gfx950 x2 correction + WRITE_SIZE; profiles/r01_v3_spread_traffic.json), if they were taken on this workload."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_v2_spread_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_v3_spread_traffic.json")) as f:
             t = json.load(f)
         w = t["workload"]
         if (w["dim"], w["bandwidth"], w["cutoff"], w["points"]) == (d, N, m, n):
@@ -152,7 +152,13 @@ def main():
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = n_gpus * n / (elapsed / args.steps) / 1e6
-        # dominant kernel: the spreading kernel (stage "spread" = exactly one launch of spread_kernel<3,10>)
+        # dominant kernel: the spreading kernel (stage "spread" = exactly one launch of it per step): the matrix-core
+        # kernel for 3-D grids of 64^3 and up with m <= 7 (unless NFFT_HIP_SPREAD selects another), else spread_kernel
+        W = 2 * m + 2
+        mfma = d == 3 and M >= 64 and W <= 16 and os.environ.get("NFFT_HIP_SPREAD", "m")[:1] not in ("l", "r")
+        kname = "spread_mfma_kernel<%d>" % W if mfma else "spread_kernel<%d,%d>" % (d, W)
+        # matrix flops the kernel issues per tap row: 3 MFMA terms x 2 x 32 x 64 x 16 per (plane, 16 points)
+        mfma_flops = n * W * 3 * 2 * 32 * 64 if mfma else 0
         sp_ms, sp_cnt = stages["spread"]
         sp_avg = sp_ms / max(sp_cnt, 1)
         alg_bytes = n * (4 * d + 4) + (M ** d) * 4  # every point read once, real grid written once
@@ -180,7 +186,7 @@ def main():
                 "parallelism": "batch-sharded x%d (one point set per GPU, no collective)" % n_gpus,
             },
             "roofline": {
-                "kernel": "spread_kernel<%d,%d>" % (d, 2 * m + 2),
+                "kernel": kname,
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -192,7 +198,7 @@ def main():
                 "launches": sp_cnt,
                 "taps_per_s": taps / (sp_avg * 1e-3) if sp_avg > 0 else 0.0,
                 "frac_of_valu_fma_peak": (taps / (sp_avg * 1e-3)) / VALU_FMA_PER_S if sp_avg > 0 else 0.0,
-                "frac_of_lds_atomic_rate": (taps / (sp_avg * 1e-3)) / LDS_ATOMIC_PER_S if sp_avg > 0 else 0.0,
+                "frac_of_mfma_f16_peak": (mfma_flops / (sp_avg * 1e-3)) / MFMA_F16_FLOPS if sp_avg > 0 else 0.0,
             },
             "stage_ms_per_launch": per_stage,
             "value_with_plan_kept_across_steps": n_gpus * n / (elapsed_cached / args.steps) / 1e6,

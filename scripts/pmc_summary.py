@@ -5,7 +5,7 @@ pat = sys.argv[2] if len(sys.argv) > 2 else ""
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].split("(")[0][-60:]
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][-60:]
         if pat and pat not in r["Kernel_Name"]:
             continue
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -18,6 +18,6 @@ for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if pat and pat not in r["Kernel_Name"]:
             continue
-        dur[r["Kernel_Name"].split("(")[0][-60:]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        dur[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][-60:]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     for k, v in dur.items():
         print("%-60s n=%d mean %.1f us" % (k, len(v), sum(v) / len(v)))
