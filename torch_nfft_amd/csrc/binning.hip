@@ -11,8 +11,9 @@
 
 namespace nfft {
 
-constexpr int kSortBlockPoints = 4096;  // points per workgroup in the first-level passes
-constexpr int kSortThreads = 256;
+constexpr int kSortBlockPoints = 16384; // points per workgroup in the first-level passes (long runs per bin: the
+                                        // scatter writes 16-byte records, ~18 per (workgroup, bin) at C3)
+constexpr int kSortThreads = 512;
 constexpr int kMaxPencilsLds = 8192;    // first-level bins that fit an LDS histogram
 
 PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)

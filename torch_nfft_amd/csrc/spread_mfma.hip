@@ -151,11 +151,11 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    // (no test for zero: a plane that received points has few zero cells, and the test costs as much
+                    // instruction issue as the atomic)
                     const float v = (t == 0 ? acc0[reg] : acc1[reg]) * zscale;
-                    if (v != 0.0f) {
-                        const int gr = wrap_near(tb1 - m + row, g.M);
-                        atomicAdd(gplane + ((int64_t)gz * g.M + gr) * g.M + gc, v);
-                    }
+                    const int gr = wrap_near(tb1 - m + row, g.M);
+                    atomicAdd(gplane + ((int64_t)gz * g.M + gr) * g.M + gc, v);
                 }
             }
             acc0 = 0.0f;
