@@ -18,6 +18,7 @@
 // Why: ds_add_f32 is unusable on gfx950 and the f64 LDS atomic bounds spread.hip at ~3 ms for 1e10 taps
 // (DESIGN.md section 4); here the taps cost 30 CU-cycles per point on the matrix pipe.
 #include <climits>
+#include <cstdlib>
 
 #include "common.h"
 #include "kernels.h"
@@ -370,7 +371,27 @@ template <int W>
 static int launch_mfma_t(const Geom &g, const int *to, const float *spos, const float *xs, const float *maxabs,
                          int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream)
 {
-    int seg_slabs = kMaxSegSlabs;
+    // Slabs swept by one workgroup: about 5-6 workgroups per CU balance the tail of the launch against the 2m+1 halo
+    // planes every segment flushes on top of its own (measured at C3: 86 slabs 7 % faster than 128, 43 in between).
+    static const int ncu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        return v;
+    }();
+    const int64_t pencils = (int64_t)g.nta[1] * g.nta[2] * nplanes;
+    int nseg_lo = (g.M + kMaxSegSlabs - 1) / kMaxSegSlabs, nseg_hi = g.M / 32 > 0 ? g.M / 32 : 1;
+    if (nseg_hi < nseg_lo) nseg_hi = nseg_lo;
+    int64_t want = (int64_t)(5.4 * ncu / (double)pencils + 0.5);
+    if (want < nseg_lo) want = nseg_lo;
+    if (want > nseg_hi) want = nseg_hi;
+    int seg_slabs = (int)((g.M + want - 1) / want);
+    if (const char *env = std::getenv("NFFT_HIP_SEG_SLABS")) {  // tuning knob
+        const int v = std::atoi(env);
+        if (v >= 16 && v <= kMaxSegSlabs) seg_slabs = v;
+    }
+    if (seg_slabs > kMaxSegSlabs) seg_slabs = kMaxSegSlabs;
     if (seg_slabs > g.M) seg_slabs = g.M;
     const int nsegm = (g.M + seg_slabs - 1) / seg_slabs;
     const dim3 blocks((unsigned)(g.nta[1] * g.nta[2] * nsegm), (unsigned)nplanes);
