@@ -96,7 +96,9 @@ interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
             for (int r = 0; r < 2; ++r) {
                 const int t = tid + r * kGmThreads;
                 const bool live = t < ntask;
-                const int cg = t & 7, row = (t >> 3) & 31, z = pz + (t >> 8);
+                // a wave's 64 tasks: 16 rows x 4 column groups (half rows of 128 contiguous bytes in HBM; 16
+                // consecutive lanes write 16 consecutive 16-byte LDS slots: no bank conflicts)
+                const int cg = ((t >> 4) & 3) + 4 * ((t >> 7) & 1), row = (t & 15) + 16 * ((t >> 6) & 1), z = pz + (t >> 8);
                 const int64_t gz = wrap(z, M);
                 const int64_t g1 = wrap_near(tb1 - m + row, M);
                 const float *const grow = gplane + (gz * M + g1) * M;
@@ -121,7 +123,8 @@ interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
             for (int r = 0; r < 2; ++r) {
                 const int t = tid + r * kGmThreads;
                 if (t < ntask) {
-                    const int cg = t & 7, row = (t >> 3) & 31, slot = (pz + (t >> 8)) & (kRing - 1);
+                    const int cg = ((t >> 4) & 3) + 4 * ((t >> 7) & 1), row = (t & 15) + 16 * ((t >> 6) & 1);
+                    const int slot = (pz + (t >> 8)) & (kRing - 1);
                     // power-of-two scale: max |G| of the plane tile lands in [1024, 2048).  Odd planes are stored
                     // negated (and un-negated through pinv): the MFMA accumulation truncates with a small
                     // sign-independent bias (scripts/ubench/mfma_bias.hip) that cancels over the alternating planes
