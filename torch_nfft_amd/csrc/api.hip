@@ -133,6 +133,16 @@ int spread_any(const Geom &g, const PlanLayout &L, const void *plan, const float
     return launch_spread(g, L, plan, xs, n, Cr, p0, np, grid, s);
 }
 
+// own pruned row passes instead of rocFFT's for the contiguous axis (NFFT_HIP_ROCFFT_ROWS=1 keeps rocFFT)
+bool own_row_passes(const Geom &g)
+{
+    static const bool off = [] {
+        const char *env = std::getenv("NFFT_HIP_ROCFFT_ROWS");
+        return env && env[0] == '1';
+    }();
+    return !off && rowfft_supported(g);
+}
+
 bool colfft_enabled()
 {
     const char *env = std::getenv("NFFT_HIP_NO_COLFFT");
@@ -305,8 +315,10 @@ static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64
         const int64_t np = std::min(c.chunk_planes, c.total_planes - p0);
         if (int rc = spread_any(c.g, c.L, plan, xs, c.n, c.Cr, p0, np, grid, s)) return rc;
         if (c.colfft) {
-            { StageTimer t(kStageFft, s); if (int rc = fft_execute(kR2CRows, c.g.dim, c.g.M, np, grid, spec, work, c.work_bytes, s)) return rc; }
-            { StageTimer t(kStageDeconv, s); if (int rc = launch_colfft_adjoint(c.g, spec, ws + c.off_col, c.chunk_planes, c.C, x_is_complex, real_output, p0, np, y, s)) return rc; }
+            const bool own_rows = own_row_passes(c.g);
+            if (own_rows) { StageTimer t(kStageFft, s); if (int rc = launch_row_r2c(c.g, grid, ws + c.off_col, c.chunk_planes, np, spec, s)) return rc; }
+            else { StageTimer t(kStageFft, s); if (int rc = fft_execute(kR2CRows, c.g.dim, c.g.M, np, grid, spec, work, c.work_bytes, s)) return rc; }
+            { StageTimer t(kStageDeconv, s); if (int rc = launch_colfft_adjoint(c.g, spec, own_rows, ws + c.off_col, c.chunk_planes, c.C, x_is_complex, real_output, p0, np, y, s)) return rc; }
         } else {
             { StageTimer t(kStageFft, s); if (int rc = fft_execute(kR2C, c.g.dim, c.g.M, np, grid, spec, work, c.work_bytes, s)) return rc; }
             { StageTimer t(kStageDeconv, s); if (int rc = launch_deconv_adjoint(c.g, spec, c.C, x_is_complex, real_output, p0, np, y, s)) return rc; }
@@ -341,8 +353,10 @@ static int forward_impl(const nfft_hip_problem *p, const float *pos, const int64
     for (int64_t p0 = 0; p0 < c.total_planes; p0 += c.chunk_planes) {
         const int64_t np = std::min(c.chunk_planes, c.total_planes - p0);
         if (c.colfft) {
-            { StageTimer t(kStageDeconv, s); if (int rc = launch_colfft_forward(c.g, xhat, ws + c.off_col, c.chunk_planes, c.C, x_is_complex, real_output, p0, np, spec, s)) return rc; }
-            { StageTimer t(kStageFft, s); if (int rc = fft_execute(kC2RRows, c.g.dim, c.g.M, np, spec, grid, work, c.work_bytes, s)) return rc; }
+            const bool own_rows = own_row_passes(c.g);
+            { StageTimer t(kStageDeconv, s); if (int rc = launch_colfft_forward(c.g, xhat, ws + c.off_col, c.chunk_planes, c.C, x_is_complex, real_output, p0, np, spec, own_rows, s)) return rc; }
+            if (own_rows) { StageTimer t(kStageFft, s); if (int rc = launch_row_c2r(c.g, spec, ws + c.off_col, c.chunk_planes, np, grid, s)) return rc; }
+            else { StageTimer t(kStageFft, s); if (int rc = fft_execute(kC2RRows, c.g.dim, c.g.M, np, spec, grid, work, c.work_bytes, s)) return rc; }
         } else {
             { StageTimer t(kStageDeconv, s); if (int rc = launch_deconv_forward(c.g, xhat, c.C, x_is_complex, real_output, p0, np, spec, s)) return rc; }
             { StageTimer t(kStageFft, s); if (int rc = fft_execute(kC2R, c.g.dim, c.g.M, np, spec, grid, work, c.work_bytes, s)) return rc; }

@@ -27,6 +27,7 @@ constexpr int kFftThreads = 256;
 struct ColGeom {
     int M, logM, N, H;  // H = N/2
     int Mh;             // M/2 + 1
+    int SR;             // row stride of the axis-2 half spectrum S: Mh (rocFFT rows) or KC (own pruned row passes)
     int KC;             // kept k2 columns: 0..H
     int NB;             // band+ rows: N + 1
     int NC, logNC;      // columns per tile
@@ -212,12 +213,12 @@ adj_axis1_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__rest
     const int u0 = blockIdx.y;
     const int64_t plane = blockIdx.z;
     stage_twiddles(ltw, tw, cg.M, tid);
-    const float2 *src = S + ((plane * cg.M + u0) * cg.M) * cg.Mh;
+    const float2 *src = S + ((plane * cg.M + u0) * cg.M) * cg.SR;
     batched_fill<16>(cg.M << cg.logNC, tid,
                      [&](int idx) {
                          const int col = idx & (cg.NC - 1), u1 = idx >> cg.logNC;
                          const int k2 = c0 + col;
-                         return k2 < cg.KC ? src[(int64_t)u1 * cg.Mh + k2] : make_float2(0.f, 0.f);
+                         return k2 < cg.KC ? src[(int64_t)u1 * cg.SR + k2] : make_float2(0.f, 0.f);
                      },
                      [&](int idx, float2 v) { buf[idx] = v; });
     lds_fft<false>(buf, ltw, cg, tid);
@@ -369,11 +370,12 @@ fwd_axis1_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__rest
     const int c0 = blockIdx.x << cg.logNC;
     const int u0 = blockIdx.y;
     const int64_t plane = blockIdx.z;
-    float2 *dst = S + ((plane * cg.M + u0) * cg.M) * cg.Mh;
+    float2 *dst = S + ((plane * cg.M + u0) * cg.M) * cg.SR;
+    const int width = cg.SR == cg.KC ? cg.KC : cg.Mh;  // columns of S that exist (the compact layout has no zero tail)
     if (c0 >= cg.KC) {  // zero tail of the padded half spectrum
         for (int idx = tid; idx < (cg.M << cg.logNC); idx += kFftThreads) {
             const int col = idx & (cg.NC - 1), u1 = idx >> cg.logNC;
-            if (c0 + col < cg.Mh) dst[(int64_t)u1 * cg.Mh + c0 + col] = make_float2(0.f, 0.f);
+            if (c0 + col < width) dst[(int64_t)u1 * cg.SR + c0 + col] = make_float2(0.f, 0.f);
         }
         return;
     }
@@ -395,14 +397,192 @@ fwd_axis1_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__rest
     for (int idx = tid; idx < (cg.M << cg.logNC); idx += kFftThreads) {
         const int col = idx & (cg.NC - 1), u1 = idx >> cg.logNC;
         const int k2 = c0 + col;
-        if (k2 < cg.Mh) {
-            dst[(int64_t)u1 * cg.Mh + k2] =
+        if (k2 < width) {
+            dst[(int64_t)u1 * cg.SR + k2] =
                 k2 < cg.KC ? buf[(brev_row(u1, cg.logM) << cg.logNC) + col] : make_float2(0.f, 0.f);
         }
     }
 }
 
-ColGeom make_col_geom(const Geom &g, bool two_buffers)
+// ---- axis 2 (contiguous rows): pruned real <-> half-complex transforms, one wave per row ---------------------
+// The M real samples of a row are packed as L = M/2 complex numbers z[n] = x[2n] + i x[2n+1]; one L-point complex FFT
+// in the wave's private LDS (same radix-8/4 butterflies as the column passes, no workgroup barrier) plus the split
+//     X[k] = (Z[k] + conj Z[L-k]) / 2 - i W_M^k (Z[k] - conj Z[L-k]) / 2,      k = 0 .. N/2   (the band; W_M = e^{-2 pi i / M})
+// gives the kept half-spectrum columns directly: one pass over the grid (rocFFT needs two and writes / reads the
+// M/2+1 - (N/2+1) columns nobody uses).  The inverse direction builds Z from the band (zero beyond it) and ends
+// with x[2n] = Re z[n], x[2n+1] = Im z[n]; both are unnormalised like rocFFT's.
+// A wave transforms RP = 512 / L consecutive rows at once (its LDS region always holds 512 complex numbers): the
+// radix-8 stages then have 64 butterflies, one per lane, and RP rows' worth of loads are in flight.
+constexpr int kWaveCplx = 512;
+constexpr int kRowWaves = 4;       // waves per workgroup
+constexpr int kRowRounds = 4;      // rounds (of RP rows) per wave
+
+// LDS index swizzle of the per-wave buffer: the butterflies of the later stages touch elements 4, 8 or 32 apart,
+// which without it land in the same banks (up to 16-way conflicts).  Bits 4..2 are XORed with bits 7..5 and bits
+// 1..0 with bits 3..2: every stage's 64 lanes then spread over all 32 eight-byte bank slots.  The map is linear over
+// GF(2), so zsw(a | b) = zsw(a) ^ zsw(b) for disjoint a, b: one XOR per butterfly leg.
+__device__ __host__ constexpr int zsw(int i) { return i ^ ((i >> 3) & 0x1c) ^ ((i >> 2) & 3); }
+
+// one radix-R step on blocks of 2^LOGLB elements over the wave's 512-element buffer; ltw = exp(-2 pi i e / M), e < M
+template <bool INV, int R, int LOGLB, int LOGM>
+__device__ __forceinline__ void wave_fft_stage(float2 *z, const float2 *ltw, int lane)
+{
+    constexpr int logR = R == 8 ? 3 : 2;
+    constexpr int logLs = LOGLB - logR, Ls = 1 << logLs;
+    constexpr int logT = LOGM - LOGLB;  // W_Lb^{jq} = W_M^{jq 2^logT}
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t0 = 0; t0 < (kWaveCplx >> logR); t0 += 64) {
+        const int t = t0 + lane;
+        const int j = t & (Ls - 1);
+        const int p0 = zsw(((t >> logLs) << LOGLB) + j);
+        float2 x[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) x[q] = z[p0 ^ zsw(q * Ls)];
+        if (R == 8) {
+            dft8<INV>(reinterpret_cast<float2(&)[8]>(x));
+        } else {
+            dft4<INV>(x[0], x[1], x[2], x[3]);
+        }
+        z[p0] = x[0];
+        if (logLs == 0) {
+#pragma unroll
+            for (int q = 1; q < R; ++q) z[p0 ^ zsw(q * Ls)] = x[q];
+        } else {
+            const int e1 = j << logT;
+#pragma unroll
+            for (int q = 1; q < R; ++q) {
+                float2 w = ltw[(q * e1) & ((1 << LOGM) - 1)];
+                if (INV) w.y = -w.y;
+                z[p0 ^ zsw(q * Ls)] = cmul(x[q], w);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// L-point FFTs (L = 2^LOGL = M/2) of the RP rows in the wave's buffer; X[k] ends up at rev[k] inside its row
+template <bool INV, int LOGL>
+__device__ __forceinline__ void wave_fft(float2 *z, const float2 *ltw, int lane)
+{
+    constexpr int LOGM = LOGL + 1;
+    if constexpr (LOGL == 6) {
+        wave_fft_stage<INV, 8, 6, LOGM>(z, ltw, lane); wave_fft_stage<INV, 8, 3, LOGM>(z, ltw, lane);
+    } else if constexpr (LOGL == 7) {
+        wave_fft_stage<INV, 8, 7, LOGM>(z, ltw, lane); wave_fft_stage<INV, 4, 4, LOGM>(z, ltw, lane);
+        wave_fft_stage<INV, 4, 2, LOGM>(z, ltw, lane);
+    } else if constexpr (LOGL == 8) {
+        wave_fft_stage<INV, 8, 8, LOGM>(z, ltw, lane); wave_fft_stage<INV, 8, 5, LOGM>(z, ltw, lane);
+        wave_fft_stage<INV, 4, 2, LOGM>(z, ltw, lane);
+    } else {
+        wave_fft_stage<INV, 8, 9, LOGM>(z, ltw, lane); wave_fft_stage<INV, 8, 6, LOGM>(z, ltw, lane);
+        wave_fft_stage<INV, 8, 3, LOGM>(z, ltw, lane);
+    }
+}
+
+// LDS of the row kernels: full twiddle table, digit-reversal table, the waves' buffers
+template <int LOGL>
+struct RowLds {
+    float2 tw[2 << LOGL];                 // exp(-2 pi i e / M), e < M
+    float2 z[kRowWaves][kWaveCplx];
+    unsigned short rev[1 << LOGL];        // row-local position of X[k] after wave_fft
+};
+
+template <int LOGL>
+__device__ __forceinline__ void row_tables(RowLds<LOGL> &S, const float2 *__restrict__ tw, int tid)
+{
+    constexpr int L = 1 << LOGL, M = 2 * L;
+    for (int e = tid; e < M; e += kRowWaves * 64) {
+        float2 w = tw[e & (L - 1)];  // the global table covers e < M/2; the other half is its negative
+        if (e >= L) w = make_float2(-w.x, -w.y);
+        S.tw[e] = w;
+    }
+    for (int k = tid; k < L; k += kRowWaves * 64) S.rev[k] = (unsigned short)brev_row(k, LOGL);
+    __syncthreads();
+}
+
+// grid rows [nrows][M] real  ->  S[nrows][KC] complex
+template <int LOGL>
+__global__ void __launch_bounds__(kRowWaves * 64)
+row_r2c_kernel(int KC, int64_t nrows, const float2 *__restrict__ tw, const float *__restrict__ grid, float2 *__restrict__ out)
+{
+    constexpr int L = 1 << LOGL, M = 2 * L, RP = kWaveCplx / L;
+    __shared__ RowLds<LOGL> S;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2 *z = S.z[wave];
+    row_tables<LOGL>(S, tw, tid);
+    const int64_t row0 = ((int64_t)blockIdx.x * kRowWaves + wave) * kRowRounds * RP;
+    for (int r = 0; r < kRowRounds; ++r) {
+        const int64_t row = row0 + (int64_t)r * RP;
+        if (row >= nrows) break;
+        const int nr = (int)min((int64_t)RP, nrows - row);  // rows of this round (all RP except at the very end)
+        const float2 *src = (const float2 *)(grid + row * M);
+#pragma unroll
+        for (int n0 = 0; n0 < kWaveCplx; n0 += 64) {
+            const int n = n0 + lane;
+            z[zsw(n)] = n < nr * L ? src[n] : make_float2(0.f, 0.f);
+        }
+        wave_fft<false, LOGL>(z, S.tw, lane);
+        for (int rr = 0; rr < nr; ++rr) {
+            float2 *dst = out + (row + rr) * KC;
+            for (int k = lane; k < KC; k += 64) {
+                const float2 a = z[zsw(rr * L + S.rev[k])];
+                float2 b = z[zsw(rr * L + S.rev[(L - k) & (L - 1)])];
+                b.y = -b.y;  // conj Z[L - k]
+                const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+                const float2 o = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
+                const float2 wo = cmul(S.tw[k], o);
+                dst[k] = make_float2(e.x + wo.y, e.y - wo.x);  // e - i w o
+            }
+        }
+    }
+}
+
+// S[nrows][KC] complex (zero beyond the band)  ->  grid rows [nrows][M] real
+template <int LOGL>
+__global__ void __launch_bounds__(kRowWaves * 64)
+row_c2r_kernel(int KC, int64_t nrows, const float2 *__restrict__ tw, const float2 *__restrict__ in, float *__restrict__ grid)
+{
+    constexpr int L = 1 << LOGL, M = 2 * L, RP = kWaveCplx / L;
+    __shared__ RowLds<LOGL> S;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2 *z = S.z[wave];
+    row_tables<LOGL>(S, tw, tid);
+    const int64_t row0 = ((int64_t)blockIdx.x * kRowWaves + wave) * kRowRounds * RP;
+    for (int r = 0; r < kRowRounds; ++r) {
+        const int64_t row = row0 + (int64_t)r * RP;
+        if (row >= nrows) break;
+        const int nr = (int)min((int64_t)RP, nrows - row);
+        const float2 *src = in + row * KC;
+#pragma unroll 4
+        for (int n0 = 0; n0 < kWaveCplx; n0 += 64) {
+            // Z[k] = (X[k] + conj X[L-k]) + i conj(W_M^k) (X[k] - conj X[L-k]),  X = 0 beyond the band
+            const int n = n0 + lane;
+            const int rr = n >> LOGL, k = n & (L - 1);
+            const bool live = rr < nr;
+            const float2 a = (live && k < KC) ? src[rr * KC + k] : make_float2(0.f, 0.f);
+            float2 b = (live && (L - k) < KC) ? src[rr * KC + L - k] : make_float2(0.f, 0.f);
+            b.y = -b.y;
+            const float2 sum = make_float2(a.x + b.x, a.y + b.y), dif = make_float2(a.x - b.x, a.y - b.y);
+            float2 w = S.tw[k];
+            w.y = -w.y;
+            const float2 wd = cmul(w, dif);
+            z[zsw(n)] = make_float2(sum.x - wd.y, sum.y + wd.x);  // sum + i w dif
+        }
+        wave_fft<true, LOGL>(z, S.tw, lane);
+        float2 *dst = (float2 *)(grid + row * M);
+#pragma unroll
+        for (int n0 = 0; n0 < kWaveCplx; n0 += 64) {
+            const int n = n0 + lane;
+            const int rr = n >> LOGL, k = n & (L - 1);
+            if (rr < nr) dst[n] = z[zsw(rr * L + S.rev[k])];
+        }
+    }
+}
+
+ColGeom make_col_geom(const Geom &g, bool two_buffers, bool compact)
 {
     ColGeom cg;
     cg.M = g.M;
@@ -412,6 +592,7 @@ ColGeom make_col_geom(const Geom &g, bool two_buffers)
     cg.H = g.N / 2;
     cg.Mh = g.M / 2 + 1;
     cg.KC = cg.H + 1;
+    cg.SR = compact ? cg.KC : cg.Mh;
     cg.NB = g.N + 1;
     // tile of NC columns: M * NC * 8 bytes per buffer, at most ~64 KB so that two workgroups share a CU
     int nc = 16;
@@ -453,8 +634,8 @@ static float2 *twiddle_ptr(const Geom &g, int64_t nplanes, void *scratch)
     return (float2 *)((char *)scratch + align_up(nplanes * (int64_t)g.M * (g.N + 1) * (g.N / 2 + 1) * 8, 256));
 }
 
-int launch_colfft_adjoint(const Geom &g, const float2 *spec, void *scratch, int64_t scratch_planes, int64_t C,
-                          int x_is_complex, int real_output, int64_t plane0, int64_t nplanes, void *y,
+int launch_colfft_adjoint(const Geom &g, const float2 *spec, bool compact, void *scratch, int64_t scratch_planes,
+                          int64_t C, int x_is_complex, int real_output, int64_t plane0, int64_t nplanes, void *y,
                           hipStream_t stream)
 {
     if (nplanes <= 0) return 0;
@@ -462,14 +643,14 @@ int launch_colfft_adjoint(const Geom &g, const float2 *spec, void *scratch, int6
     float2 *tw = twiddle_ptr(g, scratch_planes, scratch);
     hipLaunchKernelGGL(twiddle_kernel, dim3((g.M / 2 + 255) / 256), dim3(256), 0, stream, tw, g.M);
     {
-        const ColGeom cg = make_col_geom(g, false);
+        const ColGeom cg = make_col_geom(g, false, compact);
         const dim3 grid((cg.KC + cg.NC - 1) / cg.NC, g.M, (unsigned)nplanes);
         allow_lds(adj_axis1_kernel, col_lds_bytes(cg, false));
         hipLaunchKernelGGL(adj_axis1_kernel, grid, dim3(kFftThreads), col_lds_bytes(cg, false), stream, cg, tw, spec, T);
     }
     {
         const bool two = x_is_complex != 0;
-        const ColGeom cg = make_col_geom(g, two);
+        const ColGeom cg = make_col_geom(g, two, compact);
         const int ppc = two ? 2 : 1;
         const int64_t col0 = plane0 / ppc, ncols = nplanes / ppc;
         const dim3 grid((cg.KC + cg.NC - 1) / cg.NC, cg.NB, (unsigned)ncols);
@@ -491,14 +672,14 @@ int launch_colfft_adjoint(const Geom &g, const float2 *spec, void *scratch, int6
 }
 
 int launch_colfft_forward(const Geom &g, const void *xhat, void *scratch, int64_t scratch_planes, int64_t C,
-                          int x_is_complex, int real_output, int64_t plane0, int64_t nplanes, float2 *spec,
+                          int x_is_complex, int real_output, int64_t plane0, int64_t nplanes, float2 *spec, bool compact,
                           hipStream_t stream)
 {
     if (nplanes <= 0) return 0;
     float2 *T = (float2 *)scratch;
     float2 *tw = twiddle_ptr(g, scratch_planes, scratch);
     hipLaunchKernelGGL(twiddle_kernel, dim3((g.M / 2 + 255) / 256), dim3(256), 0, stream, tw, g.M);
-    const ColGeom cg = make_col_geom(g, false);
+    const ColGeom cg = make_col_geom(g, false, compact);
     const size_t lds = col_lds_bytes(cg, false);
     const int ppc = real_output ? 1 : 2;
     allow_lds(fwd_axis0_kernel<true>, lds);
@@ -510,11 +691,63 @@ int launch_colfft_forward(const Geom &g, const void *xhat, void *scratch, int64_
         else hipLaunchKernelGGL((fwd_axis0_kernel<false>), grid, dim3(kFftThreads), lds, stream, cg, tw, xhat, C, ppc, plane0, T);
     }
     {
-        const dim3 grid((cg.Mh + cg.NC - 1) / cg.NC, g.M, (unsigned)nplanes);
+        const dim3 grid(((compact ? cg.KC : cg.Mh) + cg.NC - 1) / cg.NC, g.M, (unsigned)nplanes);
         hipLaunchKernelGGL(fwd_axis1_kernel, grid, dim3(kFftThreads), lds, stream, cg, tw, T, spec);
     }
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+bool rowfft_supported(const Geom &g)
+{
+    // one wave per row: M/2 in {64, 128, 256, 512} complex points; part of the pruned column-pass pipeline
+    return colfft_supported(g) && g.M >= 128 && g.M <= 1024;
+}
+
+template <int LOGL>
+static void launch_rows_t(bool c2r, const Geom &g, int64_t nrows, const float2 *tw, const void *in, void *out,
+                          hipStream_t stream)
+{
+    const int64_t per_wg = (int64_t)kRowWaves * kRowRounds * (kWaveCplx >> LOGL);
+    const dim3 blocks((unsigned)((nrows + per_wg - 1) / per_wg));
+    if (c2r)
+        hipLaunchKernelGGL((row_c2r_kernel<LOGL>), blocks, dim3(kRowWaves * 64), 0, stream, g.N / 2 + 1, nrows, tw,
+                           (const float2 *)in, (float *)out);
+    else
+        hipLaunchKernelGGL((row_r2c_kernel<LOGL>), blocks, dim3(kRowWaves * 64), 0, stream, g.N / 2 + 1, nrows, tw,
+                           (const float *)in, (float2 *)out);
+}
+
+static int launch_rows(bool c2r, const Geom &g, int64_t nplanes, const float2 *tw, const void *in, void *out,
+                       hipStream_t stream)
+{
+    const int64_t nrows = nplanes * g.M * g.M;
+    switch (g.M) {
+    case 128: launch_rows_t<6>(c2r, g, nrows, tw, in, out, stream); break;
+    case 256: launch_rows_t<7>(c2r, g, nrows, tw, in, out, stream); break;
+    case 512: launch_rows_t<8>(c2r, g, nrows, tw, in, out, stream); break;
+    case 1024: launch_rows_t<9>(c2r, g, nrows, tw, in, out, stream); break;
+    default: set_error("row passes support M = 128 .. 1024"); return 1;
+    }
+    NFFT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_row_r2c(const Geom &g, const float *grid, void *scratch, int64_t scratch_planes, int64_t nplanes,
+                   float2 *spec, hipStream_t stream)
+{
+    if (nplanes <= 0) return 0;
+    float2 *tw = twiddle_ptr(g, scratch_planes, scratch);
+    hipLaunchKernelGGL(twiddle_kernel, dim3((g.M / 2 + 255) / 256), dim3(256), 0, stream, tw, g.M);
+    return launch_rows(false, g, nplanes, tw, grid, spec, stream);
+}
+
+int launch_row_c2r(const Geom &g, const float2 *spec, void *scratch, int64_t scratch_planes, int64_t nplanes,
+                   float *grid, hipStream_t stream)
+{
+    if (nplanes <= 0) return 0;
+    float2 *tw = twiddle_ptr(g, scratch_planes, scratch);  // written by launch_colfft_forward on the same stream
+    return launch_rows(true, g, nplanes, tw, spec, grid, stream);
 }
 
 } // namespace nfft

@@ -56,12 +56,20 @@ int fft_execute(FftKind kind, int dim, int M, int64_t nplanes, void *in, void *o
 // colfft.hip: pruned strided passes over axes 1 and 0 fused with the roll-off (3-D, power-of-two M)
 bool colfft_supported(const Geom &g);
 int64_t colfft_scratch_bytes(const Geom &g, int64_t nplanes);
-int launch_colfft_adjoint(const Geom &g, const float2 *spec, void *scratch, int64_t scratch_planes, int64_t C,
-                          int x_is_complex, int real_output, int64_t plane0, int64_t nplanes, void *y,
+// `compact`: the axis-2 half spectrum holds only the N/2+1 kept columns per row (own row passes below) instead of
+// rocFFT's M/2+1
+int launch_colfft_adjoint(const Geom &g, const float2 *spec, bool compact, void *scratch, int64_t scratch_planes,
+                          int64_t C, int x_is_complex, int real_output, int64_t plane0, int64_t nplanes, void *y,
                           hipStream_t stream);
 int launch_colfft_forward(const Geom &g, const void *xhat, void *scratch, int64_t scratch_planes, int64_t C,
-                          int x_is_complex, int real_output, int64_t plane0, int64_t nplanes, float2 *spec,
+                          int x_is_complex, int real_output, int64_t plane0, int64_t nplanes, float2 *spec, bool compact,
                           hipStream_t stream);
+// pruned real <-> half-complex row passes (axis 2), one wave per row; M in {128 .. 1024}
+bool rowfft_supported(const Geom &g);
+int launch_row_r2c(const Geom &g, const float *grid, void *scratch, int64_t scratch_planes, int64_t nplanes,
+                   float2 *spec, hipStream_t stream);
+int launch_row_c2r(const Geom &g, const float2 *spec, void *scratch, int64_t scratch_planes, int64_t nplanes,
+                   float *grid, hipStream_t stream);
 
 // api.hip: optional per-stage GPU timing with HIP events on the caller's stream (nfft_hip_profile_*)
 enum Stage { kStagePlan = 0, kStageGather, kStageZero, kStageSpread, kStageFft, kStageDeconv, kStageInterp, kNumStages };
