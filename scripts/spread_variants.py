@@ -24,12 +24,14 @@ for it in range(5):
     best = min(best, (t1 - t0) * 1e3)
 print("%s: %.3f ms (gather+memset+spread), grid sum %.6g" % (os.environ.get("NFFT_HIP_LIB", "default"), best, float(grid.double().sum())), flush=True)
 if hasattr(lib, "nfft_dbg_read"):
-    buf = (ctypes.c_ulonglong * 8)()
+    buf = (ctypes.c_ulonglong * 16)()
     lib.nfft_dbg_read(buf)  # clear
     _lib.check(lib.nfft_hip_spread(ctypes.byref(prob), p(plan), p(x), 1, p(grid), p(scratch), s))
     torch.cuda.synchronize()
     lib.nfft_dbg_read(buf)
-    v = list(buf)
-    nw, steps = v[6], v[7]
-    print("waves %d, steps/wave %.1f; per wave-step (memtime ticks): stage %.0f acc %.0f build %.0f barrier %.0f; loop/wave %.0f, final flush %.0f"
-          % (nw, steps / nw, v[0] / steps, v[1] / steps, v[2] / steps, v[3] / steps, v[4] / nw, v[5] / nw))
+    for role, base in (("plane owners", 0), ("builders", 8)):
+        v = list(buf)[base:base + 8]
+        nw, steps = v[6], v[7]
+        if nw:
+            print("%s: waves %d, steps/wave %.1f; per wave-step (memtime ticks): stage %.0f acc %.0f build %.0f barrier %.0f; loop/wave %.0f, final flush %.0f"
+                  % (role, nw, steps / nw, v[0] / steps, v[1] / steps, v[2] / steps, v[3] / steps, v[4] / nw, v[5] / nw))

@@ -59,6 +59,8 @@ __device__ __forceinline__ void lds_dma_dword(const float *gsrc, const float *ld
                  : "memory");
 }
 __device__ __forceinline__ void wait_lds_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// all but the newest request (4 LDS-DMA instructions) have landed
+__device__ __forceinline__ void wait_lds_dma_but_newest() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
 // workgroup barrier that leaves global traffic (LDS-DMA, flush atomics) in flight
 __device__ __forceinline__ void barrier_lds_only() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -73,9 +75,9 @@ template <int W>
 struct __align__(16) MfmaLds {
     MfmaOps<W> ops[2];
     MfmaStage stag[2];
-    float raw[4][kSlots];                 // landing zone of the LDS-DMA: pos0, pos1, pos2, x of the next batch
-    int raw_have[kSlots];
-    int raw_slab[kNKB];
+    float raw[2][4][kSlots];              // landing zones of the LDS-DMA (batch b uses b & 1): pos0, pos1, pos2, x
+    int raw_have[2][kSlots];
+    int raw_slab[2][kNKB];
     int task_counter[2];
     int2 sched[kMaxSegSlabs + 8];         // per slab: {K-blocks before it, point offset}; padded with the totals
 };
@@ -187,13 +189,16 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     const int total = L.sched[nslab].x;
     const int nbatch = (total + kNKB - 1) / kNKB;
 
-    // ---- staging of a batch: thread -> (K-block, point).  The points of batch i + 3 are requested (LDS-DMA into
-    // L.raw) while batch i is accumulated, and converted to (cell, fraction) form one step later.
+    // ---- staging of a batch: thread -> (K-block, point).  The points of batch i + 4 are requested (LDS-DMA into
+    // L.raw[i & 1]) while batch i is accumulated and converted to (cell, fraction) form two steps later: under the
+    // atomic traffic of the flushes a load takes longer than one step.  Every request issues exactly four DMA
+    // instructions per wave (lanes without a point read a dummy address), so that the consumer can wait with a count.
     int cur = 0;  // slab of this thread's previous K-block (K-blocks only move forward)
     auto stage_request = [&](const int batch) {
         const int j = st / kKB, i = st - j * kKB;
         const int q = batch * kNKB + j;
-        int have = 0, slab = INT_MAX;
+        const int buf = batch & 1;
+        int have = 0, slab = INT_MAX, idx = 0;
         if (q < total) {
             // sched[lo].x <= q < sched[lo + 1].x; probe four slabs ahead per LDS round trip
             int lo = cur;
@@ -209,34 +214,36 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
             }
             cur = lo;
             slab = sb + lo;
-            const int idx = e0.y + kKB * (q - e0.x) + i;
+            idx = e0.y + kKB * (q - e0.x) + i;
             have = idx < e1.y;
-            if (have) {
-                lds_dma_dword(spos + (int64_t)idx * 3 + 0, &L.raw[0][(wave - kStageWave0) * 64]);
-                lds_dma_dword(spos + (int64_t)idx * 3 + 1, &L.raw[1][(wave - kStageWave0) * 64]);
-                lds_dma_dword(spos + (int64_t)idx * 3 + 2, &L.raw[2][(wave - kStageWave0) * 64]);
-                lds_dma_dword(xcol + idx, &L.raw[3][(wave - kStageWave0) * 64]);
-            }
+            if (!have) idx = e0.y;  // any valid point: the value is not used
         }
-        L.raw_have[st] = have;
-        if (i == 0) L.raw_slab[j] = slab;
+        lds_dma_dword(spos + (int64_t)idx * 3 + 0, &L.raw[buf][0][(wave - kStageWave0) * 64]);
+        lds_dma_dword(spos + (int64_t)idx * 3 + 1, &L.raw[buf][1][(wave - kStageWave0) * 64]);
+        lds_dma_dword(spos + (int64_t)idx * 3 + 2, &L.raw[buf][2][(wave - kStageWave0) * 64]);
+        lds_dma_dword(xcol + idx, &L.raw[buf][3][(wave - kStageWave0) * 64]);
+        L.raw_have[buf][st] = have;
+        if (i == 0) L.raw_slab[buf][j] = slab;
     };
-    auto stage_convert = [&](MfmaStage &S) {
-        wait_lds_dma();
+    auto stage_convert = [&](MfmaStage &S, const int batch, const bool newest_in_flight) {
+        const int buf = batch & 1;
+        // the stager waves of the 12-owner layout issue no other vector-memory traffic: a counted wait leaves the
+        // request behind this one in flight (plane-owner waves also have flush atomics outstanding: wait for all)
+        if (newest_in_flight && NOWN != 16) wait_lds_dma_but_newest(); else wait_lds_dma();
         float f0 = 0.f, f1 = 0.f, f2 = 0.f, xv = 0.f;
         int c1 = -1000, c2 = -1000;  // padding slots: outside every window
-        if (L.raw_have[st]) {
+        if (L.raw_have[buf][st]) {
             int c0;
-            split_cell(L.raw[0][st], g.M, c0, f0);
-            split_cell(L.raw[1][st], g.M, c1, f1);
-            split_cell(L.raw[2][st], g.M, c2, f2);
+            split_cell(L.raw[buf][0][st], g.M, c0, f0);
+            split_cell(L.raw[buf][1][st], g.M, c1, f1);
+            split_cell(L.raw[buf][2][st], g.M, c2, f2);
             c1 -= tb1 - m;  // row of the point's cell inside the padded pencil (tap l1 sits at row c1 - m + l1)
             c2 -= tb2 - m;
-            xv = L.raw[3][st] * inv_xscale;
+            xv = L.raw[buf][3][st] * inv_xscale;
         }
         S.f0[st] = f0; S.f1[st] = f1; S.f2[st] = f2; S.x[st] = xv;
         S.c1[st] = c1; S.c2[st] = c2;
-        if ((st & (kKB - 1)) == 0) S.slab[st / kKB] = L.raw_slab[st / kKB];  // written by this same thread
+        if ((st & (kKB - 1)) == 0) S.slab[st / kKB] = L.raw_slab[buf][st / kKB];  // written by this same thread
     };
 
     // ---- operands of a batch: three wave-sized tasks per K-block, handed out through an LDS counter so that the
@@ -339,19 +346,21 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     };
 
     // ---- software pipeline, one barrier per batch.  Step i: convert the points of batch i + 2 (requested in step
-    // i - 1) into staging buffer i & 1 (its last reader, build_operands of batch i in step i - 1, is behind the previous
-    // barrier), request batch i + 3, build the operands of batch i + 1 (buffer (i+1) & 1) and run the MFMAs of batch i.
+    // i - 2) into staging buffer i & 1 (its last reader, build_tasks of batch i in step i - 1, is behind the previous
+    // barrier), request batch i + 4, build the operands of batch i + 1 (buffer (i+1) & 1) and run the MFMAs of batch i.
+    // Requests past the last batch are dummies that keep the count of outstanding DMA instructions uniform.
     if (tid < 2) L.task_counter[tid] = 0;
     if (stager) {
         stage_request(0);
-        stage_convert(L.stag[0]);
-        if (1 < nbatch) stage_request(1);
+        stage_convert(L.stag[0], 0, false);
+        stage_request(1);
+        stage_request(2);
     }
     __syncthreads();
     for (int i = -1; i < nbatch; ++i) {
         if (stager) {
-            if (i + 2 < nbatch) stage_convert(L.stag[i & 1]);
-            if (i + 3 < nbatch) stage_request(i + 3);
+            if (i + 2 < nbatch) stage_convert(L.stag[i & 1], i + 2, true);
+            stage_request(i + 4);
         }
         if (tid == 0) L.task_counter[i & 1] = 0;  // for the next step; its last user is behind the previous barrier
         if (i >= 0 && owner) accumulate(L.ops[i & 1], min(kNKB, total - i * kNKB));
@@ -360,6 +369,8 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                         &L.task_counter[(i + 1) & 1]);
         barrier_lds_only();
     }
+    // the dummy requests of the last steps must have landed before the workgroup gives its LDS back
+    if (stager) wait_lds_dma();
     flush();
 }
 
