@@ -58,6 +58,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it brings its own libamdhip64, and the library must bind to THAT runtime (the one that owns the
+    # tensors' device context).  Loaded the other way round, libnfft_hip.so pulls in the system ROCm runtime and its
+    # first HIP call fails ("hipGetDevice failed").
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "torch_nfft_amd: %s is missing -- build it with `python torch_nfft_amd/build.py` "
