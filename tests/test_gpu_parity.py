@@ -403,6 +403,26 @@ print("RESULT", err, bool(torch.equal(y1, y2)))
     assert float(line[1]) < T1 and line[2] == "True"
 
 
+def test_package_import_before_torch():
+    """Importing the package before torch must not bind the library to a second HIP runtime (every call then failed
+    with "hipGetDevice failed"): a fresh interpreter imports torch_nfft_amd first and runs a transform."""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import torch_nfft_amd as tn
+import torch
+pos = torch.rand((500, 3), device="cuda") - 0.5
+x = torch.rand((500,), device="cuda")
+y = tn.nfft_adjoint(x, pos, None, bandwidth=16, cutoff=3)
+print("RESULT", tuple(y.shape), bool(torch.isfinite(y.abs()).all()))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "RESULT (1, 16, 16, 16) True" in out.stdout
+
+
 def test_lds_spreading_mode_matches_oracle():
     """NFFT_HIP_SPREAD=lds keeps the f64-LDS-atomic spreading kernel and the narrow pencil tiling for 3-D grids that
     would otherwise take the matrix-core kernel: adjoint and forward against the oracle."""
