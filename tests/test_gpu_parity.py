@@ -423,9 +423,12 @@ print("RESULT", tuple(y.shape), bool(torch.isfinite(y.abs()).all()))
     assert "RESULT (1, 16, 16, 16) True" in out.stdout
 
 
-def test_lds_spreading_mode_matches_oracle():
-    """NFFT_HIP_SPREAD=lds keeps the f64-LDS-atomic spreading kernel and the narrow pencil tiling for 3-D grids that
-    would otherwise take the matrix-core kernel: adjoint and forward against the oracle."""
+@pytest.mark.parametrize("env_extra", [{"NFFT_HIP_SPREAD": "lds"},
+                                       {"NFFT_HIP_GATHER": "lds", "NFFT_HIP_ROCFFT_ROWS": "1"}])
+def test_fallback_kernels_match_oracle(env_extra):
+    """The kernels the defaults replaced stay selectable and correct: NFFT_HIP_SPREAD=lds (f64-LDS-atomic spreading,
+    narrow pencil tiling), NFFT_HIP_GATHER=lds (lane-per-point interpolation on the wide tiling) and
+    NFFT_HIP_ROCFFT_ROWS=1 (rocFFT instead of the own row passes) on a 128^3 grid: adjoint and forward vs the oracle."""
     import subprocess
     import sys
     code = r'''
@@ -434,7 +437,7 @@ sys.path.insert(0, %r)
 import torch_nfft_amd as tn
 from oracle import nfft_ref
 rng = np.random.default_rng(4)
-n, N, m = 4000, 32, 4
+n, N, m = 4000, 64, 4
 pos = (rng.random((n, 3)) - 0.5).astype(np.float32)
 pos[:500] = (0.02 * rng.standard_normal((500, 3)) + 0.4999).astype(np.float32)
 x = rng.standard_normal((n, 2)).astype(np.float32)
@@ -447,7 +450,7 @@ reff = nfft_ref.nfft_forward(y.cpu().numpy(), pos, None, m=m)
 e2 = np.linalg.norm(f.cpu().numpy() - reff) / np.linalg.norm(reff)
 print("RESULT", e1, e2)
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, NFFT_HIP_SPREAD="lds")
+    env = dict(os.environ, **env_extra)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
