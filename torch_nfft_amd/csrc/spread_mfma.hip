@@ -1,4 +1,4 @@
-// Spreading on the matrix cores (3-D grids), selected by NFFT_HIP_SPREAD=mfma.
+// Spreading on the matrix cores: the default for 3-D grids of 64^3 and up with m <= 7 (wide pencil tiling).
 //
 // Same result as the reference's adjoint_window_convolution kernels (csrc/cuda/spatial_window_operations.cu:
 // 103-211).  For one grid plane z of a pencil the window sum is an outer-product accumulation
@@ -9,14 +9,17 @@
 // operands (2^11 x = hi + lo in f16; hi*hi + hi*lo + lo*hi keeps ~22 bits), fp32 accumulators in registers:
 //   * the plan is sorted by single planes ("slabs"); a K-block is 16 points of ONE slab, so the axis-0 weight of
 //     a plane is a wave-uniform row of a small table;
-//   * one workgroup (16 waves) sweeps a segment of a pencil; wave w owns the resident plane z = w (mod 16): it
-//     needs no LDS accumulator and no barrier to accumulate, flushes its 32 x 64 tile with global atomics (each
-//     instruction = two 128-byte row segments) as soon as the sweep has passed it, and moves on to plane z + 16;
-//   * per batch of 8 K-blocks the workgroup builds the operands once in LDS (psi1 table, f16-split B fragments in
-//     MFMA register order, axis-0 table); every wave whose plane lies in a K-block's window turns the psi1 rows
-//     into its A fragment (8 multiplies + f16 split) and issues 6 MFMAs.
-// Why: ds_add_f32 is unusable on gfx950 and the f64 LDS atomic bounds spread.hip at ~3 ms for 1e10 taps
-// (DESIGN.md section 4); here the taps cost 30 CU-cycles per point on the matrix pipe.
+//   * one workgroup (16 waves) sweeps a segment of a pencil.  Plane-owner wave w holds the plane z = w (mod NOWN) of
+//     the sliding window in its accumulators: no LDS accumulator, no barrier to accumulate; it flushes its 32 x 64
+//     tile with global atomics (each instruction = two 128-byte row segments) as soon as the sweep has passed it
+//     and moves on to plane z + NOWN.  NOWN = 12 for 2m+2 <= 12 -- the other four waves, one per SIMD, only stage
+//     points and build operands -- and 16 for wider windows;
+//   * per batch of 8 K-blocks the operands are built once in LDS (psi1 table, f16-split B fragments in MFMA register
+//     order, axis-0 table), one batch ahead of the MFMAs, in wave-sized tasks handed out through an LDS counter; the
+//     points themselves arrive by LDS-DMA two batches earlier.  Every owner whose plane lies in a K-block's window
+//     turns the psi1 rows into its A fragment (16 v_fma_mix) and issues 6 MFMAs.  One raw s_barrier per batch.
+// Why: ds_add_f32 is unusable on gfx950 and the f64 LDS atomic bounds spread.hip at ~3.7 ms for 1e10 taps
+// (DESIGN.md section 4); here the taps are 0.49 PFLOP of matrix work and the kernel runs 1.7 ms at C3.
 #include <climits>
 #include <cstdlib>
 
