@@ -123,7 +123,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     float xscale = 1.0f;
     {
         const float mx = *maxabs;
-        if (mx > 0.0f && mx < 3.0e38f) {
+        if (mx > 1.0e-30f && mx < 3.0e38f) {  // (tinier inputs: 1 / scale would overflow; their taps flush to zero anyway)
             int e;
             frexpf(mx, &e);
             xscale = ldexpf(1.0f, e);
