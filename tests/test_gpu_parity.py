@@ -457,6 +457,28 @@ print("RESULT", e1, e2)
     assert float(line[1]) < T1 and float(line[2]) < T1
 
 
+@pytest.mark.parametrize("scale", [1e-25, 1e-8, 1e12, 1e30])
+def test_input_scale_invariance(tn, scale):
+    """The matrix-core kernels rescale their f16 operands by powers of two (max |x| for spreading, max |G| per plane
+    tile for the gather): results must scale exactly with the input over the fp32 range, and a mixed-magnitude input
+    must keep its small entries accurate relative to the total."""
+    rng = np.random.default_rng(77)
+    n, N, m = 6000, 32, 4
+    pos = (rng.random((n, 3)) - 0.5).astype(np.float32)
+    x = rng.standard_normal(n).astype(np.float32)
+    y1 = tn.nfft_adjoint(dev(x), dev(pos), None, bandwidth=N, cutoff=m)
+    ys = tn.nfft_adjoint(dev((x * np.float32(scale)).astype(np.float32)), dev(pos), None, bandwidth=N, cutoff=m)
+    assert rel_l2(host(ys) / scale, host(y1)) < 2e-6
+    f1 = tn.nfft_forward(y1, dev(pos), None, cutoff=m)
+    fs = tn.nfft_forward(y1 * scale, dev(pos), None, cutoff=m)
+    assert rel_l2(host(fs) / scale, host(f1)) < 2e-6
+    # mixed magnitudes: one huge coefficient among ordinary ones
+    xm = x.copy()
+    xm[0] = 1e6
+    ym = tn.nfft_adjoint(dev(xm), dev(pos), None, bandwidth=N, cutoff=m)
+    assert rel_l2(host(ym), nfft_ref.nfft_adjoint(xm, pos, None, N=N, m=m)) < T1
+
+
 def test_clustered_points_many_per_tile(tn):
     """All points inside one grid cell neighbourhood: stresses LDS accumulation order and the chunk sweep."""
     rng = np.random.default_rng(71)
