@@ -15,6 +15,8 @@
 //
 // "band+" is k in [-N/2, N/2]: the extra +N/2 row feeds the Hermitian mirror g_hat[-k] = conj(g_hat[k])
 // that reconstructs the k2 < 0 half of the spectrum from the stored k2 >= 0 half.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -594,9 +596,16 @@ ColGeom make_col_geom(const Geom &g, bool two_buffers, bool compact)
     cg.KC = cg.H + 1;
     cg.SR = compact ? cg.KC : cg.Mh;
     cg.NB = g.N + 1;
-    // tile of NC columns: M * NC * 8 bytes per buffer, at most ~64 KB so that two workgroups share a CU
+    // tile of NC columns: M * NC * 8 bytes per buffer.  32 KB tiles (NC = 8 at M = 512) let four workgroups share a
+    // CU and overlap their load / transform / store phases: 6 % faster than 64 KB tiles, 16 KB tiles (64-byte row
+    // segments) lose 30 %; NFFT_HIP_COL_NC overrides.
     int nc = 16;
-    while (nc > 1 && (int64_t)g.M * nc * 8 * (two_buffers ? 2 : 1) > 65536) nc >>= 1;
+    const int64_t cap = g.M >= 1024 ? 65536 : 32768;
+    while (nc > 1 && (int64_t)g.M * nc * 8 * (two_buffers ? 2 : 1) > cap) nc >>= 1;
+    if (const char *env = std::getenv("NFFT_HIP_COL_NC")) {
+        const int v = std::atoi(env);
+        if ((v == 4 || v == 8 || v == 16) && (int64_t)g.M * v * 8 * (two_buffers ? 2 : 1) <= 131072) nc = v;
+    }
     cg.NC = nc;
     cg.logNC = 0;
     while ((1 << cg.logNC) < nc) ++cg.logNC;
