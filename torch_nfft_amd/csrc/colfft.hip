@@ -417,7 +417,7 @@ fwd_axis1_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__rest
 // radix-8 stages then have 64 butterflies, one per lane, and RP rows' worth of loads are in flight.
 constexpr int kWaveCplx = 512;
 constexpr int kRowWaves = 4;       // waves per workgroup
-constexpr int kRowRounds = 4;      // rounds (of RP rows) per wave
+constexpr int kRowRounds = 2;      // rounds (of RP rows) per wave (2 measured best: 1, 4, 8 and 2 / 8 waves lose 3-25 %)
 
 // LDS index swizzle of the per-wave buffer: the butterflies of the later stages touch elements 4, 8 or 32 apart,
 // which without it land in the same banks (up to 16-way conflicts).  Bits 4..2 are XORed with bits 7..5 and bits

@@ -14,6 +14,8 @@
 //     (psi2 on the 64 padded columns, zero outside the window) once, then for every plane of the block's window
 //     issues 12 MFMAs (4 k-steps x {hi hi, hi lo, lo hi}) and folds the 16 rows it holds with its psi1 weights;
 //   * no atomics, no cross-wave reduction: the two half-sums of a point meet in one DPP add at the end.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 #include "mfma_split.h"
@@ -36,7 +38,7 @@ template <int W>
 __global__ void __launch_bounds__(kGmThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__restrict__ perm,
                    const float *__restrict__ spos, const float *__restrict__ grid, const int Cr, const int plane0,
-                   float *__restrict__ yr)
+                   float *__restrict__ yr, const int seg_chunks, const int nsegi)
 {
     constexpr int m = W / 2 - 1;
     constexpr int TC = 17 - W;
@@ -49,8 +51,8 @@ interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: keep it in an SGPR
     const int r32 = lane & 31, h = lane >> 5;
 
-    const int seg = blockIdx.x % g.nseg;
-    const int pencil = blockIdx.x / g.nseg;
+    const int seg = blockIdx.x % nsegi;
+    const int pencil = blockIdx.x / nsegi;
     const int j2 = pencil % g.nta[2];
     const int j1 = pencil / g.nta[2];
     const int plane_local = blockIdx.y;
@@ -58,8 +60,8 @@ interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
     const int b = plane / Cr;
     const int cr = plane - b * Cr;
 
-    const int k_begin = seg * kSegChunks;
-    const int k_end = min(g.nta[0], k_begin + kSegChunks);
+    const int k_begin = seg * seg_chunks;
+    const int k_end = min(g.nta[0], k_begin + seg_chunks);
     const int bin0 = b * g.tiles_per_batch + pencil * g.np0;
     {
         int s0, e0, s1, e1;
@@ -240,7 +242,15 @@ template <int W>
 static int launch_gm_t(const Geom &g, const int *to, const int *perm, const float *spos, const float *grid, int64_t Cr,
                        int64_t plane0, int64_t nplanes, float *yr, hipStream_t stream)
 {
-    const dim3 blocks((unsigned)(g.nta[1] * g.nta[2] * g.nseg), (unsigned)nplanes);
+    // chunks swept by one workgroup (every segment starts by staging all 16 planes of its first chunk); 4 .. 37 chunks
+    // measured within run-to-run noise (1.51 - 1.60 ms at C3)
+    int seg_chunks = kSegChunks;
+    if (const char *env = std::getenv("NFFT_HIP_GATHER_SEG_CHUNKS")) {  // tuning knob
+        const int v = std::atoi(env);
+        if (v >= 1 && v <= 1024) seg_chunks = v;
+    }
+    const int nsegi = (g.nta[0] + seg_chunks - 1) / seg_chunks;
+    const dim3 blocks((unsigned)(g.nta[1] * g.nta[2] * nsegi), (unsigned)nplanes);
     static bool attr_done = false;
     if (!attr_done) {
         NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)interp_mfma_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -248,7 +258,7 @@ static int launch_gm_t(const Geom &g, const int *to, const int *perm, const floa
         attr_done = true;
     }
     hipLaunchKernelGGL((interp_mfma_kernel<W>), blocks, dim3(kGmThreads), sizeof(GatherMfmaLds), stream, g, to, perm,
-                       spos, grid, (int)Cr, (int)plane0, yr);
+                       spos, grid, (int)Cr, (int)plane0, yr, seg_chunks, nsegi);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }
