@@ -186,6 +186,36 @@ def test_edge_points_periodic_wrap(tn):
     assert rel_l2(host(yf), ndft.ndft_forward(host(ya), pos, None)) < T2[4]
 
 
+@pytest.mark.parametrize("N,m", [(32, 4), (32, 2), (40, 7), (64, 5)])
+def test_edge_cases_wide_tiling(tn, N, m):
+    """The same edge cases on grids that take the matrix-core kernels (3-D, 2N >= 64, m <= 7): torus boundary, exact
+    grid nodes, out-of-range points, a single point, empty point sets between populated ones, every point in one cell,
+    several columns, complex coefficients."""
+    rng = np.random.default_rng(900 + N + m)
+    edge = np.array([[-0.5, -0.5, -0.5], [0.49999997, 0.49999997, 0.49999997], [0.0, 0.0, 0.0],
+                     [-0.5, 0.25, 0.125], [0.25, -0.5, 0.49999997], [0.46875, -0.46875, 0.0],
+                     [0.75, -0.75, 1.25]], np.float32)
+    same = np.tile(np.array([[0.1234, -0.3456, 0.4999]], np.float32), (40, 1))  # 40 points in one cell
+    rnd = (rng.random((300, 3)) - 0.5).astype(np.float32)
+    pos = np.concatenate([edge, same, rnd]).astype(np.float32)
+    n = pos.shape[0]
+    # point sets 0 and 3 are populated, 1, 2 and 4 are empty (batch_size = 5 comes from the last index + 1 ... so the
+    # last set has one point)
+    batch = np.zeros(n, np.int64)
+    batch[n // 2:] = 3
+    batch[-1] = 4
+    x = (rng.standard_normal((n, 2)) + 1j * rng.standard_normal((n, 2))).astype(np.complex64)
+    ya = tn.nfft_adjoint(dev(x), dev(pos), dev(batch), bandwidth=N, cutoff=m)
+    assert ya.shape == (5, N, N, N, 2)
+    assert float(ya[1].abs().max()) == 0.0 and float(ya[2].abs().max()) == 0.0
+    assert rel_l2(host(ya), nfft_ref.nfft_adjoint(x, pos, batch, N=N, m=m)) < T1
+    yf = tn.nfft_forward(ya, dev(pos), dev(batch), cutoff=m)
+    assert rel_l2(host(yf), nfft_ref.nfft_forward(host(ya), pos, batch, m=m)) < T1
+    # a single point
+    y1 = tn.nfft_adjoint(dev(np.ones((1,), np.float32)), dev(pos[:1]), None, bandwidth=N, cutoff=m)
+    assert rel_l2(host(y1), nfft_ref.nfft_adjoint(np.ones((1,), np.float32), pos[:1], None, N=N, m=m)) < T1
+
+
 def test_empty_and_tiny_inputs(tn):
     pos = torch.zeros((0, 2), dtype=torch.float32, device="cuda")
     x = torch.zeros((0, 3), dtype=torch.float32, device="cuda")
