@@ -44,9 +44,9 @@ def parse():
 
 def measured_traffic(d, N, m, n):
     """HBM bytes per launch of the spreading kernel from the committed rocprofv3 PMC passes (FETCH_SIZE with the
-    gfx950 x2 correction + WRITE_SIZE; profiles/r01_v4_spread_traffic.json), if they were taken on this workload."""
+    gfx950 x2 correction + WRITE_SIZE; profiles/r01_v5_spread_traffic.json), if they were taken on this workload."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_v4_spread_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_v5_spread_traffic.json")) as f:
             t = json.load(f)
         w = t["workload"]
         if (w["dim"], w["bandwidth"], w["cutoff"], w["points"]) == (d, N, m, n):
