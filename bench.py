@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--bandwidth", type=int, default=256)
     ap.add_argument("--cutoff", type=int, default=4)
     ap.add_argument("--dim", type=int, default=3)
+    ap.add_argument("--dist", choices=["uniform", "clusters"], default="uniform",
+                    help="point distribution: uniform on the torus (the metric's workload) or 8 Gaussian clusters "
+                         "(sigma 0.05, SURVEY.md 8(d)'s robustness case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -106,7 +109,13 @@ def main():
     d, N, m, n = args.dim, args.bandwidth, args.cutoff, args.points
     M = 2 * N
     gen = torch.Generator(device=dev).manual_seed(20240 + rank)
-    pos = torch.rand((n, d), generator=gen, device=dev) - 0.5
+    if args.dist == "uniform":
+        pos = torch.rand((n, d), generator=gen, device=dev) - 0.5
+    else:
+        centres = torch.rand((8, d), generator=gen, device=dev) - 0.5
+        which = torch.randint(0, 8, (n,), generator=gen, device=dev)
+        pos = centres[which] + 0.05 * torch.randn((n, d), generator=gen, device=dev)
+        pos = pos - torch.floor(pos + 0.5)  # back onto the torus
     x = torch.rand((n,), generator=gen, device=dev)
 
     from torch_nfft_amd import ops
@@ -165,6 +174,8 @@ def main():
         achieved = alg_bytes / (sp_avg * 1e-3) / 1e9 if sp_avg > 0 else 0.0
         taps = n * (2 * m + 2) ** d
         per_stage = {k: (v[0] / max(v[1], 1)) for k, v in stages.items() if v[1]}
+        pipe_ms = sp_avg + per_stage.get("gather", 0.0) + per_stage.get("zero", 0.0)
+        plan_ms = per_stage.get("plan", 0.0)
         # both transforms run the point plan and an FFT: split by launch count for the report
         out = {
             "metric": "Mpoints/s (adjoint+forward, 3-D N=256 m=4)",
@@ -180,8 +191,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "C3: %d-D adjoint+forward, N=%d, m=%d, %d uniform points per GPU, batch_size=1 per GPU, "
-                            "real fp32 x, forward with real_output" % (d, N, m, n),
+                "workload": "C3: %d-D adjoint+forward, N=%d, m=%d, %d %s points per GPU, batch_size=1 per GPU, "
+                            "real fp32 x, forward with real_output" % (d, N, m, n, "uniform" if args.dist == "uniform"
+                                                                         else "clustered (8 Gaussian clusters)"),
                 "points_per_gpu": n, "bandwidth": N, "cutoff": m, "dim": d,
                 "parallelism": "batch-sharded x%d (one point set per GPU, no collective)" % n_gpus,
             },
@@ -199,6 +211,10 @@ def main():
                 "taps_per_s": taps / (sp_avg * 1e-3) if sp_avg > 0 else 0.0,
                 "frac_of_valu_fma_peak": (taps / (sp_avg * 1e-3)) / VALU_FMA_PER_S if sp_avg > 0 else 0.0,
                 "frac_of_mfma_f16_peak": (mfma_flops / (sp_avg * 1e-3)) / MFMA_F16_FLOPS if sp_avg > 0 else 0.0,
+                # SURVEY.md 8(d) "metric 2": the same bytes over every kernel between (pos, x) and the finished grid
+                # (coefficient gather + zero fill + spreading), and with the point plan on top
+                "achieved_incl_gather_zero": alg_bytes / (pipe_ms * 1e-3) / 1e9 if pipe_ms > 0 else 0.0,
+                "achieved_incl_gather_zero_plan": alg_bytes / ((pipe_ms + plan_ms) * 1e-3) / 1e9 if pipe_ms > 0 else 0.0,
             },
             "stage_ms_per_launch": per_stage,
             "value_with_plan_kept_across_steps": n_gpus * n / (elapsed_cached / args.steps) / 1e6,
