@@ -49,6 +49,18 @@ StageTimer::~StageTimer()
     if (slot >= 0) (void)hipEventRecord(g_spans[slot].stop, stream);
 }
 
+int device_cu_count()
+{
+    static const int ncu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        return v;
+    }();
+    return ncu;
+}
+
 SpreadMode spread_mode()
 {
     static const SpreadMode mode = [] {

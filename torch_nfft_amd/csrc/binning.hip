@@ -4,6 +4,7 @@
 // psi: :68-97; allocated at core_cuda.cu:188-211 and re-read 2m+2 times per axis by the spreading
 // kernel).  Here the points themselves are reordered once (three streaming passes over n points) and
 // every consumer re-derives cell index and window weights in registers.
+#include <algorithm>
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
@@ -205,6 +206,44 @@ sort2_kernel(Geom g, int64_t n, int npencils, int nblocks, const int *__restrict
     }
 }
 
+// Load-balance tables of the wide tiling (common.h): one wave per (point set, pencil), lane r = range r of the pencil.
+__global__ void __launch_bounds__(64)
+segment_split_kernel(Geom g, int npl /* point sets x pencils */, int runs, int target, const int *__restrict__ offsets,
+                     int *__restrict__ first_end /* [npl][kSegMax] */, int4 *__restrict__ overflow, int capacity)
+{
+    const int pl = blockIdx.x;
+    if (pl >= npl) return;
+    const int r = threadIdx.x;
+    if (r >= runs) return;
+    const int *off = offsets + (int64_t)pl * g.np0;  // np0 == M bins per pencil, SB == 1
+    const int seg_slabs = (g.M + runs - 1) / runs;
+    const int sb = min(r * seg_slabs, g.M), se = min(sb + seg_slabs, g.M);
+    const int o_sb = off[sb], pts = off[se] - o_sb;
+    int pieces = (int)(((int64_t)pts + target / 2) / target);
+    pieces = pieces < 1 ? 1 : (pieces > kSegPieces ? kSegPieces : pieces);
+    int slot = 0;
+    if (pieces > 1) {
+        slot = overflow ? atomicAdd(&((int *)overflow)[0], pieces - 1) : capacity;
+        if (slot + pieces - 1 > capacity) pieces = 1;  // no room (or no list): the range stays whole
+    }
+    int prev = sb;  // end of the previous piece
+    for (int p = 1; p <= pieces; ++p) {
+        int end = se;
+        if (p < pieces) {
+            const int t = o_sb + (int)((int64_t)pts * p / pieces);
+            int lo = prev, hi = se;  // smallest slab in [prev, se] whose offset is >= t
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (off[mid] >= t) hi = mid; else lo = mid + 1;
+            }
+            end = lo;
+        }
+        if (p == 1) first_end[(int64_t)pl * kSegMax + r] = end;
+        else overflow[1 + slot + (p - 2)] = make_int4(pl, prev, end, 0);
+        prev = end;
+    }
+}
+
 // xs[c, slot] = xr[perm[slot], c]  (tile-ordered, column-major copy of the real coefficient columns)
 __global__ void __launch_bounds__(256) gather_rows_kernel(const int *__restrict__ perm, const float *__restrict__ xr,
                                                          float *__restrict__ xs, int64_t n, int64_t cols,
@@ -240,6 +279,18 @@ static inline int grid_for(int64_t work, int block)
     return (int)g;
 }
 
+static void launch_segment_split(const Geom &g, int64_t n, int64_t B, const int *offsets, int *first_end,
+                                 int4 *overflow, int capacity, hipStream_t stream)
+{
+    const int64_t pencils = (int64_t)g.nta[1] * g.nta[2], npl = pencils * B;
+    const int ncu = device_cu_count();
+    const int runs = seg_base_runs(n, B, pencils, g.M, ncu);
+    const int target = (int)std::min<int64_t>(seg_target_points(n, B, ncu), int64_t(1) << 30);
+    if (npl > 0)
+        hipLaunchKernelGGL(segment_split_kernel, dim3((unsigned)npl), dim3(64), 0, stream, g, (int)npl, runs, target,
+                           offsets, first_end, overflow, capacity);
+}
+
 int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, const int64_t *batch, int64_t n, int64_t B,
                        void *plan, hipStream_t stream)
 {
@@ -265,6 +316,11 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
                            npencils, nblocks, hscan, tmp);
         hipLaunchKernelGGL(sort2_kernel, dim3(npencils), dim3(kSortThreads), (size_t)g.l1bins * g.SB * 4, stream, g, n,
                            npencils, nblocks, hscan, tmp, offsets, perm, spos);
+        if (g.wide) {
+            // the record area is free now: it holds the overflow list of the load-balance split
+            NFFT_HIP_CHECK(hipMemsetAsync(tmp, 0, 16, stream));
+            launch_segment_split(g, n, B, offsets, cursor, (int4 *)tmp, (int)std::min<int64_t>(n - 1, 1 << 28), stream);
+        }
         NFFT_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -283,6 +339,8 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
         hipLaunchKernelGGL(bin_fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, g, pos, batch, n, B, offsets,
                            cursor, perm, spos);
     }
+    // (no record area in this path: ranges stay whole; the cursors are no longer needed)
+    if (g.wide) launch_segment_split(g, n, B, offsets, cursor, nullptr, 0, stream);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -99,7 +99,7 @@ inline Geom make_geom(int dim, int64_t N, int64_t m)
         if (live) g.cells *= g.M;
     }
     // 16 waves hold 16 resident planes: the axis-0 window (2m+2 planes) has to fit
-    g.wide = dim == 3 && spread_mode() == kSpreadMfma && g.M >= 64 && g.W <= 16;
+    g.wide = dim == 3 && spread_mode() == kSpreadMfma && g.M >= 64 && g.M <= 1024 && g.W <= 16;
     const TileCfg tc = tile_cfg(dim, g.W, g.wide != 0);
     g.Ta[0] = tc.TC;
     g.Ta[1] = tc.T1;
@@ -209,6 +209,30 @@ __device__ __forceinline__ int sub_of_cells(const Geom &g, const int cell[3])
 
 // ---- plan layout -----------------------------------------------------------
 // [ tile_offset int32[ntiles*SB+1] | cursor int32[ntiles] | perm int32[n] | spos float[n*dim] | scan temp | sort scratch ]
+// Wide tiling, load balance of the matrix-core kernels: a pencil is swept in `runs` equal ranges of slabs (one
+// workgroup each, as many as give ~5.4 workgroups per CU for an average pencil).  Ranges that hold far more points
+// than average (clustered inputs) are cut further by point count at plan time: the workgroup of the range keeps the
+// first piece (its end slab is stored in the plan's `cursor` area, kSegMax ints per pencil), the other pieces go to
+// an overflow list in the plan's `tmp` area ([0] = {count}, then {point set * pencils + pencil, first slab, end
+// slab, 0}) that a second, persistent launch walks.
+constexpr int kSegMax = 32;      // most ranges per pencil
+constexpr int kSegPieces = 16;   // most pieces a range is cut into
+inline int64_t seg_target_points(int64_t n, int64_t nsets, int ncu)
+{
+    const double per_set = (double)n / (double)(nsets > 0 ? nsets : 1);
+    const int64_t t = (int64_t)(per_set / (5.4 * (ncu > 0 ? ncu : 256)) + 0.5);
+    return t < 2048 ? 2048 : t;
+}
+inline int seg_base_runs(int64_t n, int64_t nsets, int64_t pencils, int M, int ncu)
+{
+    const double avg = (double)n / (double)((nsets > 0 ? nsets : 1) * (pencils > 0 ? pencils : 1));
+    int64_t r = (int64_t)(avg / (double)seg_target_points(n, nsets, ncu) + 0.5);
+    const int64_t lo = (M + 127) / 128, hi = M / 32 > lo ? M / 32 : lo;  // a range holds 32 .. 128 slabs
+    r = r < lo ? lo : (r > hi ? hi : r);
+    return (int)(r > kSegMax ? kSegMax : r);
+}
+int device_cu_count();  // api.hip
+
 struct PlanLayout {
     int64_t ntiles;
     int64_t npencils, nblocks;  // two-level sort geometry

@@ -20,6 +20,7 @@
 //     turns the psi1 rows into its A fragment (16 v_fma_mix) and issues 6 MFMAs.  One raw s_barrier per batch.
 // Why: ds_add_f32 is unusable on gfx950 and the f64 LDS atomic bounds spread.hip at ~3.7 ms for 1e10 taps
 // (DESIGN.md section 4); here the taps are 0.49 PFLOP of matrix work and the kernel runs 1.7 ms at C3.
+#include <algorithm>
 #include <climits>
 #include <cstdlib>
 
@@ -35,7 +36,7 @@ constexpr int kKB = 16;        // points per K-block (the MFMA K dimension)
 constexpr int kNKB = 8;        // K-blocks per batch
 constexpr int kSlots = kKB * kNKB;
 constexpr int kMfmaThreads = 1024;
-constexpr int kMaxSegSlabs = 128;
+constexpr int kMaxSegSlabs = 128;   // slabs of one work item (a range of M / runs slabs or a piece of it)
 constexpr int kPsiStride = 20; // floats per row of the psi1 table (16 + 4: conflict-free ds_read_b128 over rows)
 
 // Operands of one batch of K-blocks, double-buffered: while the waves run the MFMAs of batch i they already build
@@ -85,11 +86,12 @@ struct __align__(16) MfmaLds {
     int2 sched[kMaxSegSlabs + 8];         // per slab: {K-blocks before it, point offset}; padded with the totals
 };
 
-template <int W>
+template <int W, bool OVERFLOW>
 __global__ void __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *__restrict__ spos,
                    const float *__restrict__ xs, const float *__restrict__ maxabs, const int64_t n, const int Cr,
-                   const int plane0, float *__restrict__ grid, const int seg_slabs, const int nsegm)
+                   const int plane0, float *__restrict__ grid, const int seg_slabs, const int nsegm,
+                   const int *__restrict__ first_end, const int4 *__restrict__ overflow)
 {
     constexpr int m = W / 2 - 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -100,20 +102,37 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: keep it in an SGPR
     const int r32 = lane & 31, h = lane >> 5;
 
-    const int seg = blockIdx.x % nsegm;
-    const int pencil = blockIdx.x / nsegm;
-    const int j2 = pencil % g.nta[2];
-    const int j1 = pencil / g.nta[2];
     const int plane_local = blockIdx.y;
     const int plane = plane0 + plane_local;
     const int b = plane / Cr;
     const int cr = plane - b * Cr;
+    const int pencils = g.nta[1] * g.nta[2];
 
-    const int sb = seg * seg_slabs;
-    const int se = min(g.M, sb + seg_slabs);
+    // ---- work items.  Primary launch (overflow == nullptr): workgroup (pencil, range) sweeps the first piece of its
+    // range of seg_slabs slabs (all of it unless the plan cut the range because it is dense).  Overflow launch: a
+    // persistent grid walks the plan's list of the other pieces (clustered inputs; empty for uniform ones).
+    // (two instantiations: the primary one is straight-line code -- the item loop costs registers)
+    const int n_items = OVERFLOW ? overflow[0].x : 1;
+    for (int item = OVERFLOW ? (int)blockIdx.x : 0; item < n_items; item += OVERFLOW ? (int)gridDim.x : 1) {
+    if (OVERFLOW && item != (int)blockIdx.x) __syncthreads();  // the previous item is done with the LDS
+    int pencil, sb, se;
+    if constexpr (OVERFLOW) {
+        const int4 it = overflow[1 + item];
+        if (it.x / pencils != b) continue;  // another point set's piece
+        pencil = it.x % pencils;
+        sb = it.y;
+        se = it.z;
+    } else {
+        pencil = blockIdx.x / nsegm;
+        const int seg = blockIdx.x % nsegm;
+        sb = min(seg * seg_slabs, g.M);
+        se = sb < g.M ? first_end[(int64_t)(b * pencils + pencil) * kSegMax + seg] : sb;
+    }
+    const int j2 = pencil % g.nta[2];
+    const int j1 = pencil / g.nta[2];
     const int nslab = se - sb;
     const int bin0 = b * g.tiles_per_batch + pencil * g.np0;  // np0 == M: one plan bin per slab
-    if (tile_offsets[bin0 + sb] == tile_offsets[bin0 + se]) return;
+    if (nslab <= 0 || tile_offsets[bin0 + sb] == tile_offsets[bin0 + se]) continue;
 
     const int tb1 = j1 * g.Ta[1], tb2 = j2 * g.Ta[2];
     const float sc = win_exp_scale(m);
@@ -375,6 +394,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     // the dummy requests of the last steps must have landed before the workgroup gives its LDS back
     if (stager) wait_lds_dma();
     flush();
+    }  // work items
 }
 
 } // namespace
@@ -382,41 +402,38 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
 bool spread_mfma_supported(const Geom &g) { return g.dim == 3 && g.wide; }
 
 template <int W>
-static int launch_mfma_t(const Geom &g, const int *to, const float *spos, const float *xs, const float *maxabs,
-                         int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream)
+static int launch_mfma_t(const Geom &g, const PlanLayout &L, const void *plan, const int *to, const float *spos,
+                         const float *xs, const float *maxabs, int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes,
+                         float *grid, hipStream_t stream)
 {
-    // Slabs swept by one workgroup: about 5-6 workgroups per CU balance the tail of the launch against the 2m+1 halo
-    // planes every segment flushes on top of its own (measured at C3: 86 slabs 7 % faster than 128, 43 in between).
-    static const int ncu = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-            v = 256;
-        return v;
-    }();
-    const int64_t pencils = (int64_t)g.nta[1] * g.nta[2] * nplanes;
-    int nseg_lo = (g.M + kMaxSegSlabs - 1) / kMaxSegSlabs, nseg_hi = g.M / 32 > 0 ? g.M / 32 : 1;
-    if (nseg_hi < nseg_lo) nseg_hi = nseg_lo;
-    int64_t want = (int64_t)(5.4 * ncu / (double)pencils + 0.5);
-    if (want < nseg_lo) want = nseg_lo;
-    if (want > nseg_hi) want = nseg_hi;
-    int seg_slabs = (int)((g.M + want - 1) / want);
-    if (const char *env = std::getenv("NFFT_HIP_SEG_SLABS")) {  // tuning knob
-        const int v = std::atoi(env);
-        if (v >= 16 && v <= kMaxSegSlabs) seg_slabs = v;
-    }
-    if (seg_slabs > kMaxSegSlabs) seg_slabs = kMaxSegSlabs;
-    if (seg_slabs > g.M) seg_slabs = g.M;
-    const int nsegm = (g.M + seg_slabs - 1) / seg_slabs;
-    const dim3 blocks((unsigned)(g.nta[1] * g.nta[2] * nsegm), (unsigned)nplanes);
+    // Ranges per pencil: about 5-6 workgroups per CU balance the tail of the launch against the 2m+1 halo planes
+    // every range flushes on top of its own (measured at C3: 6 ranges 7 % faster than 4, 12 in between).  The count
+    // is a function of the plan's sizes only, because the plan's load-balance tables are built for it (common.h).
+    const int64_t pencils = (int64_t)g.nta[1] * g.nta[2];
+    int64_t nsets = g.tiles_per_batch > 0 ? L.ntiles / g.tiles_per_batch : 1;
+    if (nsets < 1) nsets = 1;
+    const int nsegm = seg_base_runs(n, nsets, pencils, g.M, device_cu_count());
+    const int seg_slabs = (g.M + nsegm - 1) / nsegm;
+    const dim3 blocks((unsigned)(pencils * nsegm), (unsigned)nplanes);
     static bool attr_done = false;  // one workgroup per CU: the double-buffered operands take most of the 160 KB LDS
     if (!attr_done) {
-        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)spread_mfma_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)sizeof(MfmaLds<W>)));
+        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)spread_mfma_kernel<W, false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MfmaLds<W>)));
+        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)spread_mfma_kernel<W, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MfmaLds<W>)));
         attr_done = true;
     }
-    hipLaunchKernelGGL((spread_mfma_kernel<W>), blocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to, spos, xs, maxabs, n,
-                       (int)Cr, (int)plane0, grid, seg_slabs, nsegm);
+    const char *base = (const char *)plan;
+    const int *first_end = (const int *)(base + L.off_cursor);
+    hipLaunchKernelGGL((spread_mfma_kernel<W, false>), blocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to, spos,
+                       xs, maxabs, n, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, (const int4 *)nullptr);
+    if (L.two_level) {
+        // the pieces the plan cut off dense ranges (none for uniform inputs: the workgroups then leave at once)
+        const int4 *overflow = (const int4 *)(base + L.off_tmp);
+        const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
+        hipLaunchKernelGGL((spread_mfma_kernel<W, true>), oblocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to, spos,
+                           xs, maxabs, n, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, overflow);
+    }
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -429,14 +446,14 @@ int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, con
     const float *spos = (const float *)(base + L.off_spos);
     if (nplanes <= 0 || n <= 0) return 0;
     switch (g.m) {
-    case 1: return launch_mfma_t<4>(g, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
-    case 2: return launch_mfma_t<6>(g, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
-    case 3: return launch_mfma_t<8>(g, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
-    case 4: return launch_mfma_t<10>(g, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
-    case 5: return launch_mfma_t<12>(g, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
-    case 6: return launch_mfma_t<14>(g, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
-    case 7: return launch_mfma_t<16>(g, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
-    case 8: return launch_mfma_t<18>(g, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
+    case 1: return launch_mfma_t<4>(g, L, plan, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
+    case 2: return launch_mfma_t<6>(g, L, plan, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
+    case 3: return launch_mfma_t<8>(g, L, plan, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
+    case 4: return launch_mfma_t<10>(g, L, plan, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
+    case 5: return launch_mfma_t<12>(g, L, plan, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
+    case 6: return launch_mfma_t<14>(g, L, plan, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
+    case 7: return launch_mfma_t<16>(g, L, plan, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
+    case 8: return launch_mfma_t<18>(g, L, plan, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
     }
     set_error("cutoff m must be in 1..8");
     return 1;
