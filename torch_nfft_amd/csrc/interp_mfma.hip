@@ -14,6 +14,7 @@
 //     (psi2 on the 64 padded columns, zero outside the window) once, then for every plane of the block's window
 //     issues 12 MFMAs (4 k-steps x {hi hi, hi lo, lo hi}) and folds the 16 rows it holds with its psi1 weights;
 //   * no atomics, no cross-wave reduction: the two half-sums of a point meet in one DPP add at the end.
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -34,11 +35,12 @@ struct __align__(16) GatherMfmaLds {
     float pinv[kRing];            // what one unit of the scaled plane is worth, times the B operand scale
 };
 
-template <int W>
+template <int W, bool OVERFLOW>
 __global__ void __launch_bounds__(kGmThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__restrict__ perm,
                    const float *__restrict__ spos, const float *__restrict__ grid, const int Cr, const int plane0,
-                   float *__restrict__ yr, const int seg_chunks, const int nsegi)
+                   float *__restrict__ yr, const int seg_slabs, const int nsegm, const int *__restrict__ first_end,
+                   const int4 *__restrict__ overflow)
 {
     constexpr int m = W / 2 - 1;
     constexpr int TC = 17 - W;
@@ -51,23 +53,41 @@ interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: keep it in an SGPR
     const int r32 = lane & 31, h = lane >> 5;
 
-    const int seg = blockIdx.x % nsegi;
-    const int pencil = blockIdx.x / nsegi;
-    const int j2 = pencil % g.nta[2];
-    const int j1 = pencil / g.nta[2];
     const int plane_local = blockIdx.y;
     const int plane = plane0 + plane_local;
     const int b = plane / Cr;
     const int cr = plane - b * Cr;
+    const int pencils = g.nta[1] * g.nta[2];
 
-    const int k_begin = seg * seg_chunks;
-    const int k_end = min(g.nta[0], k_begin + seg_chunks);
+    // ---- work items: the same ranges of slabs (and, for dense ranges, pieces from the plan's overflow list) as the
+    // spreading kernel (spread_mfma.hip); an item owns the chunks whose first slab lies in its range.
+    const int n_items = OVERFLOW ? overflow[0].x : 1;
+    for (int item = OVERFLOW ? (int)blockIdx.x : 0; item < n_items; item += OVERFLOW ? (int)gridDim.x : 1) {
+    if (OVERFLOW && item != (int)blockIdx.x) __syncthreads();  // the previous item is done with the LDS
+    int pencil, sb, se;
+    if constexpr (OVERFLOW) {
+        const int4 it = overflow[1 + item];
+        if (it.x / pencils != b) continue;  // another point set's piece
+        pencil = it.x % pencils;
+        sb = it.y;
+        se = it.z;
+    } else {
+        pencil = blockIdx.x / nsegm;
+        const int seg = blockIdx.x % nsegm;
+        sb = min(seg * seg_slabs, g.M);
+        se = sb < g.M ? first_end[(int64_t)(b * pencils + pencil) * kSegMax + seg] : sb;
+    }
+    const int j2 = pencil % g.nta[2];
+    const int j1 = pencil / g.nta[2];
+    const int k_begin = (sb + TC - 1) / TC;
+    const int k_end = min(g.nta[0], (se + TC - 1) / TC);
+    if (k_begin >= k_end) continue;
     const int bin0 = b * g.tiles_per_batch + pencil * g.np0;
     {
         int s0, e0, s1, e1;
         chunk_range(g, tile_offsets, bin0, k_begin, s0, e0);
         chunk_range(g, tile_offsets, bin0, k_end - 1, s1, e1);
-        if (s0 == e1) return;  // no points in this segment
+        if (s0 == e1) continue;  // no points in these chunks
     }
 
     const int tb1 = j1 * g.Ta[1], tb2 = j2 * g.Ta[2];
@@ -232,6 +252,7 @@ interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
             if (valid && h == 0) yr[(int64_t)perm[j] * Cr + cr] = y * norm;
         }
     }
+    }  // work items
 }
 
 } // namespace
@@ -239,26 +260,36 @@ interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
 bool interp_mfma_supported(const Geom &g) { return g.dim == 3 && g.wide; }
 
 template <int W>
-static int launch_gm_t(const Geom &g, const int *to, const int *perm, const float *spos, const float *grid, int64_t Cr,
-                       int64_t plane0, int64_t nplanes, float *yr, hipStream_t stream)
+static int launch_gm_t(const Geom &g, const PlanLayout &L, const void *plan, const int *to, const int *perm,
+                       const float *spos, const float *grid, int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes,
+                       float *yr, hipStream_t stream)
 {
-    // chunks swept by one workgroup (every segment starts by staging all 16 planes of its first chunk); 4 .. 37 chunks
-    // measured within run-to-run noise (1.51 - 1.60 ms at C3)
-    int seg_chunks = kSegChunks;
-    if (const char *env = std::getenv("NFFT_HIP_GATHER_SEG_CHUNKS")) {  // tuning knob
-        const int v = std::atoi(env);
-        if (v >= 1 && v <= 1024) seg_chunks = v;
-    }
-    const int nsegi = (g.nta[0] + seg_chunks - 1) / seg_chunks;
-    const dim3 blocks((unsigned)(g.nta[1] * g.nta[2] * nsegi), (unsigned)nplanes);
+    // the work decomposition of the spreading kernel (ranges of M / runs slabs per pencil + the plan's overflow list
+    // for dense ranges); every item starts by staging all 16 planes of its first chunk
+    const int64_t pencils = (int64_t)g.nta[1] * g.nta[2];
+    int64_t nsets = g.tiles_per_batch > 0 ? L.ntiles / g.tiles_per_batch : 1;
+    if (nsets < 1) nsets = 1;
+    const int nsegm = seg_base_runs(n, nsets, pencils, g.M, device_cu_count());
+    const int seg_slabs = (g.M + nsegm - 1) / nsegm;
+    const dim3 blocks((unsigned)(pencils * nsegm), (unsigned)nplanes);
     static bool attr_done = false;
     if (!attr_done) {
-        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)interp_mfma_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)sizeof(GatherMfmaLds)));
+        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)interp_mfma_kernel<W, false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GatherMfmaLds)));
+        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)interp_mfma_kernel<W, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GatherMfmaLds)));
         attr_done = true;
     }
-    hipLaunchKernelGGL((interp_mfma_kernel<W>), blocks, dim3(kGmThreads), sizeof(GatherMfmaLds), stream, g, to, perm,
-                       spos, grid, (int)Cr, (int)plane0, yr, seg_chunks, nsegi);
+    const char *base = (const char *)plan;
+    const int *first_end = (const int *)(base + L.off_cursor);
+    hipLaunchKernelGGL((interp_mfma_kernel<W, false>), blocks, dim3(kGmThreads), sizeof(GatherMfmaLds), stream, g, to,
+                       perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, (const int4 *)nullptr);
+    if (L.two_level) {
+        const int4 *overflow = (const int4 *)(base + L.off_tmp);
+        const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
+        hipLaunchKernelGGL((interp_mfma_kernel<W, true>), oblocks, dim3(kGmThreads), sizeof(GatherMfmaLds), stream, g,
+                           to, perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, overflow);
+    }
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -272,13 +303,13 @@ int launch_interp_mfma(const Geom &g, const PlanLayout &L, const void *plan, con
     const float *spos = (const float *)(base + L.off_spos);
     if (nplanes <= 0 || n <= 0) return 0;
     switch (g.m) {
-    case 1: return launch_gm_t<4>(g, to, perm, spos, grid, Cr, plane0, nplanes, yr, stream);
-    case 2: return launch_gm_t<6>(g, to, perm, spos, grid, Cr, plane0, nplanes, yr, stream);
-    case 3: return launch_gm_t<8>(g, to, perm, spos, grid, Cr, plane0, nplanes, yr, stream);
-    case 4: return launch_gm_t<10>(g, to, perm, spos, grid, Cr, plane0, nplanes, yr, stream);
-    case 5: return launch_gm_t<12>(g, to, perm, spos, grid, Cr, plane0, nplanes, yr, stream);
-    case 6: return launch_gm_t<14>(g, to, perm, spos, grid, Cr, plane0, nplanes, yr, stream);
-    case 7: return launch_gm_t<16>(g, to, perm, spos, grid, Cr, plane0, nplanes, yr, stream);
+    case 1: return launch_gm_t<4>(g, L, plan, to, perm, spos, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 2: return launch_gm_t<6>(g, L, plan, to, perm, spos, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 3: return launch_gm_t<8>(g, L, plan, to, perm, spos, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 4: return launch_gm_t<10>(g, L, plan, to, perm, spos, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 5: return launch_gm_t<12>(g, L, plan, to, perm, spos, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 6: return launch_gm_t<14>(g, L, plan, to, perm, spos, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 7: return launch_gm_t<16>(g, L, plan, to, perm, spos, grid, n, Cr, plane0, nplanes, yr, stream);
     }
     set_error("matrix-core interpolation supports cutoff 1..7");
     return 1;
