@@ -173,7 +173,18 @@ sort2_kernel(Geom g, int64_t n, int npencils, int nblocks, const int *__restrict
     const int p1 = l1 + 1 < npencils ? hscan[(int64_t)(l1 + 1) * nblocks] : (int)n;
     for (int i = threadIdx.x; i < nt0; i += kSortThreads) lds2[i] = 0;
     __syncthreads();
-    for (int j = p0 + threadIdx.x; j < p1; j += kSortThreads) atomicAdd(&lds2[fine_key(g, tmp[j], bin_lo)], 1);
+    // (eight records per thread in flight: a dense bin of a clustered input is one workgroup's serial loop)
+    for (int j0 = p0 + threadIdx.x; j0 < p1; j0 += kSortThreads * 8) {
+        float4 rec[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = j0 + q * kSortThreads;
+            rec[q] = j < p1 ? tmp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (j0 + q * kSortThreads < p1) atomicAdd(&lds2[fine_key(g, rec[q], bin_lo)], 1);
+    }
     __syncthreads();
     // exclusive scan of the nt0 chunk counts by one wave (nt0 is small: M / TC)
     if (threadIdx.x < 64) {
@@ -196,13 +207,23 @@ sort2_kernel(Geom g, int64_t n, int npencils, int nblocks, const int *__restrict
         if (l1 == npencils - 1 && threadIdx.x == 0) offsets[obase + nt0] = (int)n;
     }
     __syncthreads();
-    for (int j = p0 + threadIdx.x; j < p1; j += kSortThreads) {
-        const float4 rec = tmp[j];
-        const int slot = p0 + atomicAdd(&lds2[fine_key(g, rec, bin_lo)], 1);
-        perm[slot] = __float_as_int(rec.w);
-        spos[(int64_t)slot * g.dim] = rec.x;
-        if (g.dim > 1) spos[(int64_t)slot * g.dim + 1] = rec.y;
-        if (g.dim > 2) spos[(int64_t)slot * g.dim + 2] = rec.z;
+    for (int j0 = p0 + threadIdx.x; j0 < p1; j0 += kSortThreads * 8) {
+        float4 recs[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = j0 + q * kSortThreads;
+            recs[q] = j < p1 ? tmp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (j0 + q * kSortThreads >= p1) continue;
+            const float4 rec = recs[q];
+            const int slot = p0 + atomicAdd(&lds2[fine_key(g, rec, bin_lo)], 1);
+            perm[slot] = __float_as_int(rec.w);
+            spos[(int64_t)slot * g.dim] = rec.x;
+            if (g.dim > 1) spos[(int64_t)slot * g.dim + 1] = rec.y;
+            if (g.dim > 2) spos[(int64_t)slot * g.dim + 2] = rec.z;
+        }
     }
 }
 
