@@ -82,21 +82,34 @@ __global__ void __launch_bounds__(256) bin_fill_kernel(Geom g, const float *__re
 //            the device, and the slice is scattered with LDS cursors -> records grouped by pencil.
 //   level 2: one workgroup per pencil counting-sorts its records by chunk in LDS and writes the final
 //            tile offsets, the tile-ordered positions and the permutation.
-__device__ __forceinline__ void point_cells(const Geom &g, const float *__restrict__ pos, int64_t i, int cell[3])
-{
-    cell[0] = cell[1] = cell[2] = 0;
-    for (int u = 0; u < g.dim; ++u) {
-        float fr;
-        split_cell(pos[i * g.dim + u], g.M, cell[u + 3 - g.dim], fr);
-    }
-}
-
 // first-level bin: (batch, pencil, segment of l1bins plan bins along axis 0)
 __device__ __forceinline__ int pencil_of(const Geom &g, const int cell[3], int64_t b)
 {
     const int pencil = ((int)b * g.nta[1] + cell[1] / g.Ta[1]) * g.nta[2] + cell[2] / g.Ta[2];
     return g.l1seg == 1 ? pencil : pencil * g.l1seg + (cell[0] / g.bin0) / g.l1bins;
 }
+
+// first-level bin of a point given by its (up to three) coordinates, internal axis order
+__device__ __forceinline__ int l1_bin_of(const Geom &g, float c0, float c1, float c2, int64_t b)
+{
+    int cell[3] = {0, 0, 0};
+    float fr;
+    if (g.dim == 3) {
+        split_cell(c0, g.M, cell[0], fr);
+        split_cell(c1, g.M, cell[1], fr);
+        split_cell(c2, g.M, cell[2], fr);
+    } else if (g.dim == 2) {
+        split_cell(c0, g.M, cell[1], fr);
+        split_cell(c1, g.M, cell[2], fr);
+    } else {
+        split_cell(c0, g.M, cell[2], fr);
+    }
+    return pencil_of(g, cell, b);
+}
+
+// The first-level passes read kSortUnroll points per thread before touching the LDS counters: a wave then keeps
+// several global loads in flight instead of one load -> atomic (-> store) chain per point.
+constexpr int kSortUnroll = 8;
 
 __global__ void __launch_bounds__(kSortThreads)
 sort1_count_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restrict__ batch, int64_t n, int64_t B,
@@ -107,12 +120,24 @@ sort1_count_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restr
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * kSortBlockPoints;
     const int64_t hi = min(n, lo + kSortBlockPoints);
-    for (int64_t i = lo + threadIdx.x; i < hi; i += kSortThreads) {
-        int cell[3];
-        point_cells(g, pos, i, cell);
-        int64_t b = batch ? batch[i] : 0;
-        b = b < 0 ? 0 : (b >= B ? B - 1 : b);
-        atomicAdd(&lds_hist[pencil_of(g, cell, b)], 1);
+    for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)kSortThreads * kSortUnroll) {
+        float c0[kSortUnroll], c1[kSortUnroll], c2[kSortUnroll];
+        int64_t bb[kSortUnroll];
+#pragma unroll
+        for (int q = 0; q < kSortUnroll; ++q) {
+            const int64_t i = i0 + (int64_t)q * kSortThreads;
+            const bool live = i < hi;
+            c0[q] = live ? pos[i * g.dim] : 0.f;
+            c1[q] = live && g.dim > 1 ? pos[i * g.dim + 1] : 0.f;
+            c2[q] = live && g.dim > 2 ? pos[i * g.dim + 2] : 0.f;
+            bb[q] = live && batch ? batch[i] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < kSortUnroll; ++q) {
+            if (i0 + (int64_t)q * kSortThreads >= hi) continue;
+            const int64_t b = bb[q] < 0 ? 0 : (bb[q] >= B ? B - 1 : bb[q]);
+            atomicAdd(&lds_hist[l1_bin_of(g, c0[q], c1[q], c2[q], b)], 1);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < npencils; i += kSortThreads) hist[(int64_t)i * nblocks + blockIdx.x] = lds_hist[i];
@@ -127,18 +152,26 @@ sort1_scatter_kernel(Geom g, const float *__restrict__ pos, const int64_t *__res
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * kSortBlockPoints;
     const int64_t hi = min(n, lo + kSortBlockPoints);
-    for (int64_t i = lo + threadIdx.x; i < hi; i += kSortThreads) {
-        int cell[3];
-        point_cells(g, pos, i, cell);
-        int64_t b = batch ? batch[i] : 0;
-        b = b < 0 ? 0 : (b >= B ? B - 1 : b);
-        const int slot = atomicAdd(&lds_cur[pencil_of(g, cell, b)], 1);
-        float4 rec;
-        rec.x = pos[i * g.dim];
-        rec.y = g.dim > 1 ? pos[i * g.dim + 1] : 0.f;
-        rec.z = g.dim > 2 ? pos[i * g.dim + 2] : 0.f;
-        rec.w = __int_as_float((int)i);
-        tmp[slot] = rec;
+    for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)kSortThreads * kSortUnroll) {
+        float c0[kSortUnroll], c1[kSortUnroll], c2[kSortUnroll];
+        int64_t bb[kSortUnroll];
+#pragma unroll
+        for (int q = 0; q < kSortUnroll; ++q) {
+            const int64_t i = i0 + (int64_t)q * kSortThreads;
+            const bool live = i < hi;
+            c0[q] = live ? pos[i * g.dim] : 0.f;
+            c1[q] = live && g.dim > 1 ? pos[i * g.dim + 1] : 0.f;
+            c2[q] = live && g.dim > 2 ? pos[i * g.dim + 2] : 0.f;
+            bb[q] = live && batch ? batch[i] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < kSortUnroll; ++q) {
+            const int64_t i = i0 + (int64_t)q * kSortThreads;
+            if (i >= hi) continue;
+            const int64_t b = bb[q] < 0 ? 0 : (bb[q] >= B ? B - 1 : bb[q]);
+            const int slot = atomicAdd(&lds_cur[l1_bin_of(g, c0[q], c1[q], c2[q], b)], 1);
+            tmp[slot] = make_float4(c0[q], c1[q], c2[q], __int_as_float((int)i));
+        }
     }
 }
 
