@@ -305,11 +305,34 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const int *__restrict_
 {
     const int64_t total = n * cols;
     float mx = 0.0f;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t slot = e / cols, c = e - slot * cols;
-        const float v = xr[(int64_t)perm[slot] * cols + c];
-        xs[c * n + slot] = v;
-        mx = fmaxf(mx, fabsf(v));
+    // eight elements per thread and step: first the eight permutation entries, then the eight (random) coefficient
+    // reads, so that a wave has 8 x 64 independent loads in flight
+    constexpr int UN = 8;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += stride * UN) {
+        int64_t src[UN];
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const int64_t e = e0 + q * stride;
+            if (e < total) {
+                const int64_t slot = e / cols, c = e - slot * cols;
+                src[q] = (int64_t)perm[slot] * cols + c;
+            } else {
+                src[q] = -1;
+            }
+        }
+        float v[UN];
+#pragma unroll
+        for (int q = 0; q < UN; ++q) v[q] = src[q] >= 0 ? xr[src[q]] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const int64_t e = e0 + q * stride;
+            if (e < total) {
+                const int64_t slot = e / cols, c = e - slot * cols;
+                xs[c * n + slot] = v[q];
+                mx = fmaxf(mx, fabsf(v[q]));
+            }
+        }
     }
     if (maxabs_bits) {
         // one atomic per workgroup; non-negative floats order like their bit patterns (NaN / inf inputs saturate the
