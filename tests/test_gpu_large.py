@@ -84,6 +84,45 @@ def test_config_c3_3d_n256_m4_10m(tn):
     assert rel_l2((y + 2 * y2).cpu().numpy(), y12.cpu().numpy()) < 2e-6
 
 
+def test_clustered_points_overflow_launch(tn):
+    """2e6 points in 8 Gaussian clusters (sigma 0.05; SURVEY 8(d)'s robustness distribution) on a 256^3 grid, two point
+    sets: dense slab ranges are cut at plan time and their extra pieces run in the second (overflow) launch of the
+    matrix-core kernels.  Adjoint on a frequency subset vs the exact NDFT, forward of a sparse spectrum vs the exact
+    sum, adjointness between the two."""
+    N, m, n = 128, 4, 2_000_000
+    gen = torch.Generator(device="cuda").manual_seed(31)
+    centres = torch.rand((8, 3), generator=gen, device="cuda") - 0.5
+    which = torch.randint(0, 8, (n,), generator=gen, device="cuda")
+    pos = centres[which] + 0.05 * torch.randn((n, 3), generator=gen, device="cuda")
+    pos = pos - torch.floor(pos + 0.5)
+    batch = (torch.arange(n, device="cuda") >= n // 3).to(torch.int64)  # two point sets of different size
+    x = torch.randn((n,), generator=gen, device="cuda")
+    y = tn.nfft_adjoint(x, pos, batch, bandwidth=N, cutoff=m)
+    assert y.shape == (2, N, N, N)
+    rng = np.random.default_rng(32)
+    freqs = rng.integers(-N // 2, N // 2, size=(32, 3))
+    for b in range(2):
+        sel = (batch == b).cpu().numpy()
+        exact = ndft.ndft_adjoint_subset(x.cpu().numpy()[sel][:, None], pos.cpu().numpy()[sel], freqs)[:, 0]
+        got = y[b].cpu().numpy()[tuple((freqs + N // 2).T)]
+        assert rel_l2(got, exact) < T2_M4
+    xh = torch.zeros((2, N, N, N), dtype=torch.complex64, device="cuda")
+    f = rng.integers(-N // 2, N // 2, size=(6, 3))
+    vals = (rng.standard_normal((2, 6)) + 1j * rng.standard_normal((2, 6))).astype(np.complex64)
+    for b in range(2):
+        for fr, v in zip(f, vals[b]):
+            xh[(b,) + tuple(fr + N // 2)] += complex(v)
+    yf = tn.nfft_forward(xh, pos, batch, cutoff=m)
+    idx = rng.integers(0, n, size=4096)
+    p = pos[idx].cpu().numpy().astype(np.float64)
+    bsel = batch[idx].cpu().numpy()
+    exact = (np.exp(-2j * np.pi * (p @ f.T.astype(np.float64))) * vals[bsel].astype(np.complex128)).sum(1)
+    assert rel_l2(yf[idx].cpu().numpy(), exact) < T2_M4
+    lhs = torch.sum(y * xh.conj())
+    rhs = torch.sum(x.to(torch.complex64) * yf.conj())
+    assert abs(complex(lhs) - complex(rhs)) < 1e-4 * abs(complex(lhs)) + 1e-2
+
+
 def test_config_c4_shape_batched_columns_chunked(tn, monkeypatch):
     """Config C4's structure (3-D N=128, m=4, several point sets x several columns) at a size that runs in seconds,
     with a chunk budget that forces the plane loop: subset of frequencies vs the exact NDFT per (batch, column)."""
