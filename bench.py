@@ -47,9 +47,9 @@ def parse():
 
 def measured_traffic(d, N, m, n):
     """HBM bytes per launch of the spreading kernel from the committed rocprofv3 PMC passes (FETCH_SIZE with the
-    gfx950 x2 correction + WRITE_SIZE; profiles/r01_v5_spread_traffic.json), if they were taken on this workload."""
+    gfx950 x2 correction + WRITE_SIZE; profiles/r01_v6_spread_traffic.json), if they were taken on this workload."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_v5_spread_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_v6_spread_traffic.json")) as f:
             t = json.load(f)
         w = t["workload"]
         if (w["dim"], w["bandwidth"], w["cutoff"], w["points"]) == (d, N, m, n):
@@ -165,7 +165,9 @@ def main():
         # kernel for 3-D grids of 64^3 and up with m <= 7 (unless NFFT_HIP_SPREAD selects another), else spread_kernel
         W = 2 * m + 2
         mfma = d == 3 and M >= 64 and W <= 16 and os.environ.get("NFFT_HIP_SPREAD", "m")[:1] not in ("l", "r")
-        kname = "spread_mfma_kernel<%d>" % W if mfma else "spread_kernel<%d,%d>" % (d, W)
+        # (the matrix-core kernel has a second, "overflow" instantiation <W, true> that is launched right after it and
+        # is empty unless the points are clustered; the stage timer covers both launches)
+        kname = "spread_mfma_kernel<%d, false>" % W if mfma else "spread_kernel<%d,%d>" % (d, W)
         # matrix flops the kernel issues per tap row: 3 MFMA terms x 2 x 32 x 64 x 16 per (plane, 16 points)
         mfma_flops = n * W * 3 * 2 * 32 * 64 if mfma else 0
         sp_ms, sp_cnt = stages["spread"]
