@@ -216,6 +216,34 @@ def test_edge_cases_wide_tiling(tn, N, m):
     assert rel_l2(host(y1), nfft_ref.nfft_adjoint(np.ones((1,), np.float32), pos[:1], None, N=N, m=m)) < T1
 
 
+def test_many_small_point_sets_wide_tiling(tn):
+    """1 500 point sets of a few points each on a 64^3 grid: more first-level sort bins than fit the LDS histogram, so
+    the plan takes the one-level (global-atomic) binning path -- without the overflow list -- under the matrix-core
+    kernels; checked on a sample of the point sets against the oracle."""
+    rng = np.random.default_rng(123)
+    B, N, m = 1500, 32, 3
+    counts = rng.integers(0, 9, size=B)
+    counts[-1] = 3  # batch_size comes from the last index
+    batch = np.repeat(np.arange(B), counts).astype(np.int64)
+    n = batch.shape[0]
+    pos = (rng.random((n, 3)) - 0.5).astype(np.float32)
+    x = rng.standard_normal(n).astype(np.float32)
+    y = tn.nfft_adjoint(dev(x), dev(pos), dev(batch), bandwidth=N, cutoff=m)
+    assert y.shape == (B, N, N, N)
+    xh = (rng.standard_normal((B, N, N, N)) + 1j * rng.standard_normal((B, N, N, N))).astype(np.complex64)
+    yf = tn.nfft_forward(dev(xh), dev(pos), dev(batch), cutoff=m)
+    yh, yfh = host(y), host(yf)
+    for b in (0, 1, 2, 700, 1498, 1499):
+        sel = batch == b
+        if sel.sum() == 0:
+            assert float(np.abs(yh[b]).max()) == 0.0
+            continue
+        ref = nfft_ref.nfft_adjoint(x[sel], pos[sel], None, N=N, m=m)[0]
+        assert rel_l2(yh[b], ref) < T1
+        reff = nfft_ref.nfft_forward(xh[b:b + 1], pos[sel], None, m=m)
+        assert rel_l2(yfh[sel], reff) < T1
+
+
 def test_empty_and_tiny_inputs(tn):
     pos = torch.zeros((0, 2), dtype=torch.float32, device="cuda")
     x = torch.zeros((0, 3), dtype=torch.float32, device="cuda")
