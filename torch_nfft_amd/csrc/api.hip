@@ -99,6 +99,14 @@ int validate(const nfft_hip_problem *p)
     if (2 * p->m + 2 > 2 * p->N) { set_error("Input mismatch: window 2m+2 exceeds the oversampled grid 2N"); return NFFT_HIP_EINVAL; }
     if (p->N > (1 << 20)) { set_error("Input mismatch: bandwidth too large"); return NFFT_HIP_EINVAL; }
     if (p->num_points >= (int64_t(1) << 31)) { set_error("Input mismatch: too many points"); return NFFT_HIP_EINVAL; }
+    {
+        // the point plan indexes its (point set, tile) bins with 32-bit integers
+        const Geom g = make_geom((int)p->dim, (int)p->N, (int)p->m);
+        if ((double)g.tiles_per_batch * (double)p->batch_size * (double)g.SB >= 2.0e9) {
+            set_error("Input mismatch: too many point sets for this grid (plan bins exceed 2^31)");
+            return NFFT_HIP_EINVAL;
+        }
+    }
     return 0;
 }
 
