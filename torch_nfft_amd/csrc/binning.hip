@@ -1,4 +1,5 @@
-// Point plan: counting sort of the points by (batch, pencil, chunk) tile.
+// Point plan: counting sort of the points by (batch, pencil, chunk) tile -- (batch, pencil, slab) for the wide tiling
+// of the matrix-core kernels, plus their load-balance tables (segment_split_kernel).
 //
 // Replaces the reference's per-point HBM temporaries (shifts: spatial_window_operations.cu:38-61,
 // psi: :68-97; allocated at core_cuda.cu:188-211 and re-read 2m+2 times per axis by the spreading
