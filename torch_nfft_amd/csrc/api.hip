@@ -338,7 +338,18 @@ static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64
             const bool own_rows = own_row_passes(c.g);
             if (own_rows) { StageTimer t(kStageFft, s); if (int rc = launch_row_r2c(c.g, grid, ws + c.off_col, c.chunk_planes, np, spec, s)) return rc; }
             else { StageTimer t(kStageFft, s); if (int rc = fft_execute(kR2CRows, c.g.dim, c.g.M, np, grid, spec, work, c.work_bytes, s)) return rc; }
-            { StageTimer t(kStageDeconv, s); if (int rc = launch_colfft_adjoint(c.g, spec, own_rows, ws + c.off_col, c.chunk_planes, c.C, x_is_complex, real_output, p0, np, y, s)) return rc; }
+            if (c.C > 1) {
+                // several columns: the passes write a planar copy (into the grid buffer, free by now), one tiled
+                // transpose brings it into the reference's column-interleaved layout
+                StageTimer t(kStageDeconv, s);
+                const int ppc_a = x_is_complex ? 2 : 1;
+                const int64_t K = c.g.N * (int64_t)c.g.N * c.g.N;
+                if (int rc = launch_colfft_adjoint(c.g, spec, own_rows, ws + c.off_col, c.chunk_planes, 1, x_is_complex, real_output, 0, np, grid, s)) return rc;
+                if (int rc = launch_column_layout(true, grid, y, K, c.C, p0 / ppc_a, np / ppc_a, real_output ? 4 : 8, s)) return rc;
+            } else {
+                StageTimer t(kStageDeconv, s);
+                if (int rc = launch_colfft_adjoint(c.g, spec, own_rows, ws + c.off_col, c.chunk_planes, c.C, x_is_complex, real_output, p0, np, y, s)) return rc;
+            }
         } else {
             { StageTimer t(kStageFft, s); if (int rc = fft_execute(kR2C, c.g.dim, c.g.M, np, grid, spec, work, c.work_bytes, s)) return rc; }
             { StageTimer t(kStageDeconv, s); if (int rc = launch_deconv_adjoint(c.g, spec, c.C, x_is_complex, real_output, p0, np, y, s)) return rc; }
@@ -374,7 +385,16 @@ static int forward_impl(const nfft_hip_problem *p, const float *pos, const int64
         const int64_t np = std::min(c.chunk_planes, c.total_planes - p0);
         if (c.colfft) {
             const bool own_rows = own_row_passes(c.g);
-            { StageTimer t(kStageDeconv, s); if (int rc = launch_colfft_forward(c.g, xhat, ws + c.off_col, c.chunk_planes, c.C, x_is_complex, real_output, p0, np, spec, own_rows, s)) return rc; }
+            if (c.C > 1) {
+                // several columns: planar copy of this chunk's columns first (the grid buffer is free until the row pass)
+                StageTimer t(kStageDeconv, s);
+                const int64_t K = c.g.N * (int64_t)c.g.N * c.g.N;
+                if (int rc = launch_column_layout(false, xhat, grid, K, c.C, p0 / ppc, np / ppc, x_is_complex ? 8 : 4, s)) return rc;
+                if (int rc = launch_colfft_forward(c.g, grid, ws + c.off_col, c.chunk_planes, 1, x_is_complex, real_output, 0, np, spec, own_rows, s)) return rc;
+            } else {
+                StageTimer t(kStageDeconv, s);
+                if (int rc = launch_colfft_forward(c.g, xhat, ws + c.off_col, c.chunk_planes, c.C, x_is_complex, real_output, p0, np, spec, own_rows, s)) return rc;
+            }
             if (own_rows) { StageTimer t(kStageFft, s); if (int rc = launch_row_c2r(c.g, spec, ws + c.off_col, c.chunk_planes, np, grid, s)) return rc; }
             else { StageTimer t(kStageFft, s); if (int rc = fft_execute(kC2RRows, c.g.dim, c.g.M, np, spec, grid, work, c.work_bytes, s)) return rc; }
         } else {

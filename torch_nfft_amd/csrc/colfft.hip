@@ -584,6 +584,51 @@ row_c2r_kernel(int KC, int64_t nrows, const float2 *__restrict__ tw, const float
     }
 }
 
+// ---- column-interleaved <-> planar copies for several coefficient columns -------------------------------
+// The reference stores spectra as [B, N^d, C] (columns innermost).  A column pass that handles one (point set,
+// column) plane would touch elements 8 C bytes apart (measured at C = 64: the last pass twice as slow).  With C > 1
+// the passes therefore work on a planar copy [column][N^d] (it lives in the grid buffer, which is free at that point
+// of either pipeline) and these tiled transposes move between the two layouts: 64 frequencies x 32 columns per
+// workgroup through LDS, contiguous runs on both sides.
+template <typename T, bool TO_INTERLEAVED>
+__global__ void __launch_bounds__(256)
+column_layout_kernel(const T *__restrict__ src, T *__restrict__ dst, int64_t K /* N^d */, int64_t C, int64_t col0,
+                     int64_t ncols)
+{
+    __shared__ T tile[32][65];
+    const int64_t k0 = (int64_t)blockIdx.x * 64;
+    const int64_t cl0 = (int64_t)blockIdx.y * 32;
+    const int tid = threadIdx.x;
+    if (TO_INTERLEAVED) {
+        // read planar rows (contiguous in k), write interleaved (contiguous in the column index)
+        for (int e = tid; e < 32 * 64; e += 256) {
+            const int cl = e >> 6, k = e & 63;
+            if (cl0 + cl < ncols && k0 + k < K) tile[cl][k] = src[(cl0 + cl) * K + k0 + k];
+        }
+        __syncthreads();
+        for (int e = tid; e < 32 * 64; e += 256) {
+            const int k = e >> 5, cl = e & 31;
+            if (cl0 + cl < ncols && k0 + k < K) {
+                const int64_t colg = col0 + cl0 + cl, b = colg / C, c = colg - b * C;
+                dst[(b * K + k0 + k) * C + c] = tile[cl][k];
+            }
+        }
+    } else {
+        for (int e = tid; e < 32 * 64; e += 256) {
+            const int k = e >> 5, cl = e & 31;
+            if (cl0 + cl < ncols && k0 + k < K) {
+                const int64_t colg = col0 + cl0 + cl, b = colg / C, c = colg - b * C;
+                tile[cl][k] = src[(b * K + k0 + k) * C + c];
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < 32 * 64; e += 256) {
+            const int cl = e >> 6, k = e & 63;
+            if (cl0 + cl < ncols && k0 + k < K) dst[(cl0 + cl) * K + k0 + k] = tile[cl][k];
+        }
+    }
+}
+
 ColGeom make_col_geom(const Geom &g, bool two_buffers, bool compact)
 {
     ColGeom cg;
@@ -757,6 +802,31 @@ int launch_row_c2r(const Geom &g, const float2 *spec, void *scratch, int64_t scr
     if (nplanes <= 0) return 0;
     float2 *tw = twiddle_ptr(g, scratch_planes, scratch);  // written by launch_colfft_forward on the same stream
     return launch_rows(true, g, nplanes, tw, spec, grid, stream);
+}
+
+// planar [ncols][N^d] <-> interleaved [B, N^d, C] for the columns col0 .. col0 + ncols (global column = b * C + c)
+int launch_column_layout(bool to_interleaved, const void *src, void *dst, int64_t K, int64_t C, int64_t col0,
+                         int64_t ncols, int elem_bytes, hipStream_t stream)
+{
+    if (ncols <= 0 || K <= 0) return 0;
+    const dim3 blocks((unsigned)((K + 63) / 64), (unsigned)((ncols + 31) / 32));
+    if (elem_bytes == 8) {
+        if (to_interleaved)
+            hipLaunchKernelGGL((column_layout_kernel<float2, true>), blocks, dim3(256), 0, stream, (const float2 *)src,
+                               (float2 *)dst, K, C, col0, ncols);
+        else
+            hipLaunchKernelGGL((column_layout_kernel<float2, false>), blocks, dim3(256), 0, stream, (const float2 *)src,
+                               (float2 *)dst, K, C, col0, ncols);
+    } else {
+        if (to_interleaved)
+            hipLaunchKernelGGL((column_layout_kernel<float, true>), blocks, dim3(256), 0, stream, (const float *)src,
+                               (float *)dst, K, C, col0, ncols);
+        else
+            hipLaunchKernelGGL((column_layout_kernel<float, false>), blocks, dim3(256), 0, stream, (const float *)src,
+                               (float *)dst, K, C, col0, ncols);
+    }
+    NFFT_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 } // namespace nfft

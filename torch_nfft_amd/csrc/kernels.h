@@ -64,6 +64,9 @@ int launch_colfft_adjoint(const Geom &g, const float2 *spec, bool compact, void 
 int launch_colfft_forward(const Geom &g, const void *xhat, void *scratch, int64_t scratch_planes, int64_t C,
                           int x_is_complex, int real_output, int64_t plane0, int64_t nplanes, float2 *spec, bool compact,
                           hipStream_t stream);
+// planar [ncols][N^d] <-> column-interleaved [B, N^d, C] copies (tiled transposes) for the column passes with C > 1
+int launch_column_layout(bool to_interleaved, const void *src, void *dst, int64_t K, int64_t C, int64_t col0,
+                         int64_t ncols, int elem_bytes, hipStream_t stream);
 // pruned real <-> half-complex row passes (axis 2), one wave per row; M in {128 .. 1024}
 bool rowfft_supported(const Geom &g);
 int launch_row_r2c(const Geom &g, const float *grid, void *scratch, int64_t scratch_planes, int64_t nplanes,
