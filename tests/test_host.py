@@ -35,7 +35,8 @@ def test_problem_validation_without_gpu():
     assert lib.nfft_hip_plan_bytes(ctypes.byref(ok)) > 1000 * 4 * 4
     for bad in [_lib.Problem(0, 10, 1, 1, 16, 3), _lib.Problem(4, 10, 1, 1, 16, 3), _lib.Problem(2, 10, 1, 1, 15, 3),
                 _lib.Problem(2, 10, 1, 1, 16, 0), _lib.Problem(2, 10, 1, 1, 16, 9), _lib.Problem(2, 10, 1, 0, 16, 3),
-                _lib.Problem(2, -1, 1, 1, 16, 3), _lib.Problem(1, 10, 1, 1, 2, 2)]:
+                _lib.Problem(2, -1, 1, 1, 16, 3), _lib.Problem(1, 10, 1, 1, 2, 2),
+                _lib.Problem(3, 10, 1, 100000, 256, 4)]:  # (point set, tile) bins beyond 32-bit indices
         assert lib.nfft_hip_plan_bytes(ctypes.byref(bad)) == -1
         assert _lib.last_error().startswith("Input mismatch")
     # error mapping: the reference raises RuntimeError("Input mismatch") (csrc/cuda/cuda_utils.cu:3)
