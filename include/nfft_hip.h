@@ -123,6 +123,28 @@ int nfft_hip_interpolate(const nfft_hip_problem *p, const void *plan, const floa
 int nfft_hip_spectral_multiply(void *yhat, const void *coeffs, int coeffs_are_complex, int64_t batch_size,
                                int64_t band_size, int64_t num_columns, void *stream);
 
+/* One-call fast summation:  y[j, c] = Re?[ sum_k coeffs[k] (sum_i x[i, c] e^{+2 pi i k.s_i}) e^{-2 pi i k.t_j} ].
+ * Replaces nfft_fastsum_cuda (csrc/cuda/core_cuda.cu:535-852), i.e. the operator
+ * torch_nfft::nfft_fastsum(sources, targets, x, coeffs, source_batch, target_batch, m) (csrc/core.cpp:108-121, 179):
+ * spreading of the sources -> inverse FFT -> product with coeffs * phi_hat_inv^2 on the band
+ * (spectral_window_operations.cu:269-402; here folded into the last spectral pass of the adjoint half) -> FFT ->
+ * interpolation at the targets.
+ *   src / tgt   the two point sets: same dim, N, m, batch_size and num_columns, their own num_points
+ *   x  [n_s, C] float32 or complex64;  coeffs [N^dim] float32 or complex64 (index l + N/2 on every axis)
+ *   y  [n_t, C] float32 when x is real (the real part, core_cuda.cu:817-821), complex64 otherwise
+ * When `targets == sources` (same pointer, same batch pointer, same count) one point plan serves both halves, as in
+ * the reference (core_cuda.cu:552-564).  The _planned variant takes existing point plans (the same pointer twice
+ * for shared points).  Workspace: nfft_hip_fastsum_workspace_bytes(src, tgt, x_is_complex, shared_points, planned). */
+int64_t nfft_hip_fastsum_workspace_bytes(const nfft_hip_problem *src, const nfft_hip_problem *tgt, int x_is_complex,
+                                         int shared_points, int planned);
+int nfft_hip_fastsum(const nfft_hip_problem *src, const float *sources, const int64_t *source_batch,
+                     const nfft_hip_problem *tgt, const float *targets, const int64_t *target_batch, const void *x,
+                     int x_is_complex, const void *coeffs, int coeffs_are_complex, void *y, void *workspace,
+                     int64_t workspace_bytes, void *stream);
+int nfft_hip_fastsum_planned(const nfft_hip_problem *src, const void *source_plan, const nfft_hip_problem *tgt,
+                             const void *target_plan, const void *x, int x_is_complex, const void *coeffs,
+                             int coeffs_are_complex, void *y, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* Coefficient set-up (csrc/cuda/kernel_coeffs.cu, drivers core_cuda.cu:855-1064).  Outputs are [N]^dim
  * arrays, index l + N/2 on every axis.
  *   gaussian_analytic_coeffs      float32:  prod_d sqrt(pi) sigma exp(-sigma^2 pi^2 l_d^2)      (kernel_coeffs.cu:6-30)

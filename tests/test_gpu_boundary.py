@@ -1,0 +1,269 @@
+"""GPU tests of the drop-in boundary itself:
+
+* the un-planned C entry points ``nfft_hip_adjoint`` / ``nfft_hip_forward`` / ``nfft_hip_fastsum`` exactly as a
+  non-torch host would call them (ctypes, raw device pointers, caller-provided workspace), on the golden vectors
+  frozen from the reference's ``torch_nfft/ndft.py`` and against the oracle;
+* the native operator registry ``core.so`` (``torch.ops.torch_nfft.*`` served by C++, not by Python);
+* the ``torch_nfft`` drop-in package name;
+* the point-plan cache across streams and the rejection of a negative batch index;
+* the batch-sharded wrapper (``torch_nfft_amd.distributed``) on one GPU: world_size 1, and every shard of a simulated
+  world computed one after the other, against the unsharded HIP call.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+from oracle import ndft, nfft_ref
+
+pytestmark = pytest.mark.gpu
+
+T1 = 2e-5
+T2 = {3: 3e-3, 4: 5e-4}
+
+
+@pytest.fixture(scope="module")
+def tn():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import torch_nfft_amd
+    return torch_nfft_amd
+
+
+def dev(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def c_adjoint(x, pos, batch, N, m, real_output=False):
+    """nfft_hip_adjoint through ctypes: numpy in, numpy out."""
+    from torch_nfft_amd import _lib
+    lib = _lib.load()
+    n, d = pos.shape
+    B = int(batch[-1]) + 1 if batch is not None else 1
+    C = int(np.prod(x.shape[1:], dtype=np.int64))
+    cplx = 1 if np.iscomplexobj(x) else 0
+    prob = _lib.Problem(d, n, C, B, N, m)
+    nbytes = lib.nfft_hip_adjoint_workspace_bytes(ctypes.byref(prob), cplx, 1 if real_output else 0)
+    assert nbytes > 0, _lib.last_error()
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    xt, pt, bt = dev(x), dev(pos), dev(batch)
+    y = torch.full((B,) + (N,) * d + x.shape[1:], float("nan"),
+                   dtype=torch.float32 if real_output else torch.complex64, device="cuda")
+    _lib.check(lib.nfft_hip_adjoint(ctypes.byref(prob), _p(pt), _p(xt), cplx, _p(bt), 1 if real_output else 0, _p(y),
+                                    _p(ws), nbytes, _stream()))
+    return host(y)
+
+
+def c_forward(xhat, pos, batch, m, real_output=False):
+    from torch_nfft_amd import _lib
+    lib = _lib.load()
+    n, d = pos.shape
+    B, N = xhat.shape[0], xhat.shape[1]
+    cols = xhat.shape[1 + d:]
+    C = int(np.prod(cols, dtype=np.int64))
+    cplx = 1 if np.iscomplexobj(xhat) else 0
+    prob = _lib.Problem(d, n, C, B, N, m)
+    nbytes = lib.nfft_hip_forward_workspace_bytes(ctypes.byref(prob), cplx, 1 if real_output else 0)
+    assert nbytes > 0, _lib.last_error()
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    xt, pt, bt = dev(xhat), dev(pos), dev(batch)
+    y = torch.full((n,) + cols, float("nan"), dtype=torch.float32 if real_output else torch.complex64, device="cuda")
+    _lib.check(lib.nfft_hip_forward(ctypes.byref(prob), _p(pt), _p(xt), cplx, _p(bt), 1 if real_output else 0, _p(y),
+                                    _p(ws), nbytes, _stream()))
+    return host(y)
+
+
+# ----------------------------------------------------------------------------- un-planned C entry points
+
+def test_c_abi_adjoint_forward_golden_g1_2d(tn):
+    g = load_golden("g1_adjoint_2d_batched")
+    y = c_adjoint(g["x"], g["pos"], g["batch"], 16, 4)
+    assert y.shape == (3, 16, 16, 10)
+    assert rel_l2(y, g["y_adjoint"]) < T2[4]
+    assert rel_l2(y, nfft_ref.nfft_adjoint(g["x"], g["pos"], g["batch"], N=16, m=4)) < T1
+    f = c_forward(y, g["pos"], g["batch"], 4)
+    assert rel_l2(f, nfft_ref.nfft_forward(y, g["pos"], g["batch"], m=4)) < T1
+    assert rel_l2(f, ndft.ndft_forward(y, g["pos"], g["batch"])) < T2[4]
+
+
+def test_c_abi_adjoint_forward_golden_g4_3d(tn):
+    g = load_golden("g4_3d_ragged")
+    for key in ("real", "complex"):
+        y = c_adjoint(g["x_" + key], g["pos"], g["batch"], 16, 4)
+        assert rel_l2(y, g["y_adjoint_" + key]) < T2[4]
+        assert rel_l2(y, nfft_ref.nfft_adjoint(g["x_" + key], g["pos"], g["batch"], N=16, m=4)) < T1
+    yr = c_adjoint(g["x_complex"], g["pos"], g["batch"], 16, 4, real_output=True)
+    assert yr.dtype == np.float32
+    assert rel_l2(yr, nfft_ref.nfft_adjoint(g["x_complex"], g["pos"], g["batch"], N=16, m=4, real_output=True)) < T1
+    f = c_forward(g["xhat"], g["pos"], g["batch"], 4)
+    assert rel_l2(f, g["y_forward"]) < T2[4]
+    assert rel_l2(f, nfft_ref.nfft_forward(g["xhat"], g["pos"], g["batch"], m=4)) < T1
+    fr = c_forward(g["xhat"], g["pos"], g["batch"], 4, real_output=True)
+    assert rel_l2(fr, nfft_ref.nfft_forward(g["xhat"], g["pos"], g["batch"], m=4, real_output=True)) < T1
+
+
+def test_c_abi_matrix_core_grid_unplanned(tn):
+    """The un-planned entry points on a grid that takes the matrix-core kernels (the plan is built into the
+    workspace by the call itself)."""
+    rng = np.random.default_rng(17)
+    n, N, m = 5000, 32, 4
+    pos = (rng.random((n, 3)) - 0.5).astype(np.float32)
+    batch = np.sort(rng.integers(0, 2, n)).astype(np.int64)
+    batch[0], batch[-1] = 0, 1
+    x = rng.standard_normal((n, 2)).astype(np.float32)
+    y = c_adjoint(x, pos, batch, N, m)
+    assert rel_l2(y, nfft_ref.nfft_adjoint(x, pos, batch, N=N, m=m)) < T1
+    f = c_forward(y, pos, batch, m, real_output=True)
+    assert rel_l2(f, nfft_ref.nfft_forward(y, pos, batch, m=m, real_output=True)) < T1
+
+
+@pytest.mark.parametrize("d,N,shared,complex_x,complex_coeffs", [(2, 16, True, False, False), (2, 16, False, True, True),
+                                                                   (3, 32, False, False, True), (3, 32, True, True, False),
+                                                                   (1, 64, False, False, False)])
+def test_c_abi_fastsum(tn, d, N, shared, complex_x, complex_coeffs):
+    """nfft_hip_fastsum, one C call: spread -> FFT -> coefficient product -> FFT -> gather (core_cuda.cu:535-852)."""
+    from torch_nfft_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(100 * d + N + shared)
+    m, B, C = 4, 2, 3
+    ns, nt = 400, 400 if shared else 650
+    def pts(n):
+        pos = ((rng.random((n, d)) - 0.5) * 0.5).astype(np.float32)
+        batch = np.sort(rng.integers(0, B, n)).astype(np.int64)
+        batch[0], batch[-1] = 0, B - 1
+        return pos, batch
+    src, sb = pts(ns)
+    tgt, tb = (src, sb) if shared else pts(nt)
+    x = rng.standard_normal((ns, C)).astype(np.float32)
+    if complex_x:
+        x = (x + 1j * rng.standard_normal((ns, C))).astype(np.complex64)
+    coeffs = rng.standard_normal((N,) * d).astype(np.float32)
+    if complex_coeffs:
+        coeffs = (coeffs + 1j * rng.standard_normal((N,) * d)).astype(np.complex64)
+    ps = _lib.Problem(d, ns, C, B, N, m)
+    pt = _lib.Problem(d, nt, C, B, N, m)
+    nbytes = lib.nfft_hip_fastsum_workspace_bytes(ctypes.byref(ps), ctypes.byref(pt), 1 if complex_x else 0,
+                                                  1 if shared else 0, 0)
+    assert nbytes > 0, _lib.last_error()
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    srct, sbt, xt, ct = dev(src), dev(sb), dev(x), dev(coeffs)
+    tgtt, tbt = (srct, sbt) if shared else (dev(tgt), dev(tb))
+    y = torch.full((nt, C), float("nan"), dtype=torch.complex64 if complex_x else torch.float32, device="cuda")
+    _lib.check(lib.nfft_hip_fastsum(ctypes.byref(ps), _p(srct), _p(sbt), ctypes.byref(pt), _p(tgtt), _p(tbt), _p(xt),
+                                    1 if complex_x else 0, _p(ct), 1 if complex_coeffs else 0, _p(y), _p(ws), nbytes,
+                                    _stream()))
+    ref = nfft_ref.nfft_fastsum(x, coeffs, src, None if shared else tgt, sb, None if shared else tb, m=m)
+    if not complex_x:
+        ref = ref.real
+    assert rel_l2(host(y), ref) < T1
+    exact = ndft.ndft_fastsum(x, coeffs, src, None if shared else tgt, sb, None if shared else tb)
+    if not complex_x:
+        exact = exact.real
+    assert rel_l2(host(y), exact) < 2e-3
+    # the operator gives the same numbers (it calls the planned variant of the same driver)
+    y2 = tn.nfft_fastsum(xt, ct, srct, None if shared else tgtt, sbt, None if shared else tbt, cutoff=m)
+    assert y2.dtype == y.dtype
+    assert rel_l2(host(y2), host(y)) < 2e-6
+
+
+# ----------------------------------------------------------------------------- native operator registry
+
+def test_operators_are_served_by_core_so(tn):
+    from torch_nfft_amd import _lib
+    assert any(os.path.realpath(p) == os.path.realpath(_lib.CORE_PATH) for p in torch.ops.loaded_libraries)
+    mapped = open("/proc/self/maps").read()
+    assert "torch_nfft_amd/core.so" in mapped and "torch_nfft_amd/libnfft_hip.so" in mapped
+    names = ["nfft_adjoint", "nfft_forward", "nfft_fastsum", "gaussian_analytic_coeffs", "gaussian_interpolated_coeffs",
+             "interpolation_grid", "radial_interpolation_grid", "interpolated_kernel_coeffs"]
+    for name in names:
+        op = getattr(torch.ops.torch_nfft, name).default
+        # registered from C++ (TORCH_LIBRARY in csrc/core.cpp): no Python kernel behind any dispatch key
+        assert not op.py_kernels, name
+    a = torch.ops.torch_nfft.gaussian_analytic_coeffs(0.2, 8, 2)
+    assert a.is_cuda and a.shape == (8, 8)
+
+
+def test_drop_in_package_name(tn):
+    """`import torch_nfft` (the reference's package name) resolves to this implementation."""
+    import torch_nfft
+    assert torch_nfft.nfft_adjoint is tn.nfft_adjoint and torch_nfft.nfft_fastsum is tn.nfft_fastsum
+    for name in ("nfft_forward", "ndft_adjoint", "ndft_forward", "ndft_fastsum", "exact_gaussian_matrix",
+                 "exact_trigonometric_matrix", "gaussian_analytic_coeffs", "GramMatrix", "AdjacencyMatrix",
+                 "GaussianKernel"):
+        assert hasattr(torch_nfft, name), name
+
+
+def test_negative_batch_index_is_rejected(tn):
+    pos = torch.zeros((4, 2), device="cuda")
+    x = torch.ones((4,), device="cuda")
+    with pytest.raises(RuntimeError, match="Input mismatch"):
+        tn.nfft_adjoint(x, pos, torch.tensor([-1, 0, 0, 1], device="cuda"), bandwidth=8, cutoff=2)
+
+
+def test_plan_cache_across_streams(tn):
+    """A plan built on one stream and consumed on another: the consumer waits for the build and the results agree."""
+    from torch_nfft_amd import ops
+    rng = np.random.default_rng(5)
+    n, N, m = 20000, 32, 4
+    pos = dev((rng.random((n, 3)) - 0.5).astype(np.float32))
+    x = dev(rng.standard_normal(n).astype(np.float32))
+    ops.plan_cache_clear()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        y1 = tn.nfft_adjoint(x, pos, None, bandwidth=N, cutoff=m)
+    h0 = ops.plan_cache_stats()["hits"]
+    with torch.cuda.stream(s2):  # no host synchronisation in between
+        y2 = tn.nfft_adjoint(x, pos, None, bandwidth=N, cutoff=m)
+        f2 = tn.nfft_forward(y2, pos, None, cutoff=m, real_output=True)
+    assert ops.plan_cache_stats()["hits"] == h0 + 2
+    torch.cuda.synchronize()
+    assert rel_l2(host(y2), host(y1)) < 2e-6
+    assert rel_l2(host(f2), nfft_ref.nfft_forward(host(y1), host(pos), None, m=m, real_output=True)) < T1
+
+
+# ----------------------------------------------------------------------------- batch-sharded wrapper on one GPU
+
+def test_sharded_wrapper_world1_and_simulated_shards(tn):
+    """torch_nfft_amd.distributed with the HIP operators: world_size 1 (no process group) equals the plain call, and
+    the shards a world of R ranks would compute -- run here one after the other on the one GPU through the wrapper's
+    own partitioning -- concatenate to the unsharded result."""
+    from torch_nfft_amd import distributed as D
+    rng = np.random.default_rng(9)
+    B, N, m, C = 5, 32, 4, 3
+    counts = np.array([700, 0, 1300, 400, 900])
+    batch = np.repeat(np.arange(B), counts).astype(np.int64)
+    n = batch.shape[0]
+    pos = (rng.random((n, 3)) - 0.5).astype(np.float32)
+    x = rng.standard_normal((n, C)).astype(np.float32)
+    xt, pt, bt = dev(x), dev(pos), dev(batch)
+    full = tn.nfft_adjoint(xt, pt, bt, bandwidth=N, cutoff=m)
+    assert rel_l2(host(full), nfft_ref.nfft_adjoint(x, pos, batch, N=N, m=m)) < T1
+    y1 = D.nfft_adjoint(xt, pt, bt, bandwidth=N, cutoff=m)  # world_size 1
+    assert torch.equal(y1, full) or rel_l2(host(y1), host(full)) < 2e-6
+    fwd_full = tn.nfft_forward(full, pt, bt, cutoff=m, real_output=True)
+    f1 = D.nfft_forward(full, pt, bt, cutoff=m, real_output=True)
+    assert rel_l2(host(f1), host(fwd_full)) < 2e-6
+    for world in (2, 3, 8):
+        slabs, rows = [], []
+        for rank in range(world):
+            slabs.append(D.shard_adjoint(xt, pt, bt, B, rank, world, bandwidth=N, cutoff=m))
+            rows.append(D.shard_forward(full, pt, bt, B, rank, world, cutoff=m, real_output=True))
+        assert [s.shape[0] for s in slabs] == [D.batch_range(B, r, world)[1] - D.batch_range(B, r, world)[0]
+                                               for r in range(world)]
+        assert rel_l2(host(torch.cat(slabs, 0)), host(full)) < 2e-6
+        assert rel_l2(host(torch.cat(rows, 0)), host(fwd_full)) < 2e-6

@@ -384,12 +384,10 @@ def test_chunked_planes_path(tn, monkeypatch):
     # budget for ~2 planes of (real grid + half spectrum)
     monkeypatch.setenv("NFFT_HIP_CHUNK_BYTES", str(2 * (32 * 32 * 4 + 32 * 17 * 8) + 8))
     from torch_nfft_amd import ops
-    ops._ws_bytes_cache.clear()
     ya = tn.nfft_adjoint(dev(x), dev(pos), dev(batch), bandwidth=N, cutoff=m)
     assert rel_l2(host(ya), nfft_ref.nfft_adjoint(x, pos, batch, N=N, m=m)) < T1
     yf = tn.nfft_forward(ya, dev(pos), dev(batch), cutoff=m)
     assert rel_l2(host(yf), nfft_ref.nfft_forward(host(ya), pos, batch, m=m)) < T1
-    ops._ws_bytes_cache.clear()
 
 
 def test_full_rocfft_path_when_column_passes_disabled(tn, monkeypatch):
@@ -401,10 +399,8 @@ def test_full_rocfft_path_when_column_passes_disabled(tn, monkeypatch):
     ya = tn.nfft_adjoint(dev(x), dev(pos), dev(batch), bandwidth=16, cutoff=4)
     yf = tn.nfft_forward(ya, dev(pos), dev(batch), cutoff=4)
     monkeypatch.setenv("NFFT_HIP_NO_COLFFT", "1")
-    ops._ws_bytes_cache.clear()
     ya2 = tn.nfft_adjoint(dev(x), dev(pos), dev(batch), bandwidth=16, cutoff=4)
     yf2 = tn.nfft_forward(ya, dev(pos), dev(batch), cutoff=4)
-    ops._ws_bytes_cache.clear()
     assert rel_l2(host(ya2), host(ya)) < 2e-6
     assert rel_l2(host(yf2), host(yf)) < 2e-6
     assert rel_l2(host(ya2), nfft_ref.nfft_adjoint(x, pos, batch, N=16, m=4)) < T1

@@ -1,13 +1,16 @@
-"""Loader for the C-ABI library ``libnfft_hip.so`` (declared in ``include/nfft_hip.h``).
+"""Loader for the two native libraries: the C-ABI library ``libnfft_hip.so`` (declared in
+``include/nfft_hip.h``; bound here with ctypes for the stage-level entry points, the timers and non-torch style
+tests) and the torch operator registry ``core.so`` built on top of it (``csrc/core.cpp``), which is loaded with
+``torch.ops.load_library`` like the reference's (``torch_nfft/__init__.py:11``).
 
-The product path has no CPU fallback: if the HIP library is missing or lacks a symbol the
-import fails loudly.
+The product path has no CPU fallback: if a library is missing or lacks a symbol the import fails loudly.
 """
 import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NFFT_HIP_LIB") or os.path.join(_HERE, "libnfft_hip.so")
+CORE_PATH = os.path.join(_HERE, "core.so")
 
 ABI_VERSION = 1
 
@@ -26,6 +29,9 @@ SYMBOLS = (
     "nfft_hip_spread",
     "nfft_hip_interpolate",
     "nfft_hip_spectral_multiply",
+    "nfft_hip_fastsum_workspace_bytes",
+    "nfft_hip_fastsum",
+    "nfft_hip_fastsum_planned",
     "nfft_hip_gaussian_analytic_coeffs",
     "nfft_hip_interpolation_grid",
     "nfft_hip_coeffs_workspace_bytes",
@@ -93,6 +99,12 @@ def load():
     lib.nfft_hip_interpolate.restype = ci
     lib.nfft_hip_spectral_multiply.argtypes = [vp, vp, ci, i64, i64, i64, vp]
     lib.nfft_hip_spectral_multiply.restype = ci
+    lib.nfft_hip_fastsum_workspace_bytes.argtypes = [P, P, ci, ci, ci]
+    lib.nfft_hip_fastsum_workspace_bytes.restype = i64
+    lib.nfft_hip_fastsum.argtypes = [P, vp, vp, P, vp, vp, vp, ci, vp, ci, vp, vp, i64, vp]
+    lib.nfft_hip_fastsum.restype = ci
+    lib.nfft_hip_fastsum_planned.argtypes = [P, vp, P, vp, vp, ci, vp, ci, vp, vp, i64, vp]
+    lib.nfft_hip_fastsum_planned.restype = ci
     lib.nfft_hip_gaussian_analytic_coeffs.argtypes = [ctypes.c_double, i64, ctypes.c_int32, vp, vp]
     lib.nfft_hip_gaussian_analytic_coeffs.restype = ci
     lib.nfft_hip_interpolation_grid.argtypes = [i64, ctypes.c_int32, ci, vp, vp]
@@ -112,6 +124,27 @@ def load():
         raise ImportError("torch_nfft_amd: ABI version mismatch in %s" % LIB_PATH)
     _lib = lib
     return lib
+
+
+_core_loaded = False
+
+
+def load_core():
+    """Registers ``torch.ops.torch_nfft.*`` from ``core.so`` (after libnfft_hip.so, which it links against: the
+    library loaded above is the instance it binds to)."""
+    global _core_loaded
+    if _core_loaded:
+        return
+    load()
+    import torch
+    if not os.path.exists(CORE_PATH):
+        raise ImportError(
+            "torch_nfft_amd: %s is missing -- build it with `python torch_nfft_amd/build.py`" % CORE_PATH)
+    try:
+        torch.ops.load_library(CORE_PATH)
+    except Exception as e:  # a second provider of the torch_nfft namespace, or an unresolved symbol
+        raise ImportError("torch_nfft_amd: cannot load %s: %s" % (CORE_PATH, e)) from e
+    _core_loaded = True
 
 
 def profile_enable(on):

@@ -1,8 +1,13 @@
-"""Builds torch_nfft_amd/libnfft_hip.so (the C-ABI library of include/nfft_hip.h) for gfx950.
+"""Builds the two native libraries of the package for gfx950:
 
-Plain hipcc, no torch headers: the library's ABI is C.  Sources are compiled in parallel and
-relinked only when something changed.  Usage: ``python torch_nfft_amd/build.py [--force]`` (run as a
-script so that a stale or missing library cannot block its own rebuild through the package import).
+* ``libnfft_hip.so`` -- the C-ABI library of include/nfft_hip.h (kernels + drivers).  Plain hipcc, no torch
+  headers: the library's ABI is C.  Sources are compiled in parallel and relinked only when something changed.
+* ``core.so`` -- the torch operator registry (csrc/core.cpp: ``TORCH_LIBRARY(torch_nfft, ...)``) on top of it,
+  the counterpart of the reference's ``torch_nfft/core.so`` (setup.py:14-29, no ABI suffix).  Host code only
+  (g++ against the torch headers); it finds libnfft_hip.so next to itself (``$ORIGIN``).
+
+Usage: ``python torch_nfft_amd/build.py [--force]`` (run as a script so that a stale or missing library cannot
+block its own rebuild through the package import).
 """
 import concurrent.futures
 import os
@@ -13,6 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libnfft_hip.so")
+CORE = os.path.join(HERE, "core.so")
+CORE_SRC = os.path.join(CSRC, "core.cpp")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 SOURCES = ["api.hip", "binning.hip", "spread.hip", "spread_reg.hip", "spread_mfma.hip", "interp.hip", "interp_mfma.hip", "spectral.hip", "colfft.hip", "coeffs.hip", "fft.cpp"]
@@ -44,12 +51,33 @@ def build(force=False, verbose=True):
         results = list(ex.map(lambda s: _compile(s, force, hdr), SOURCES))
     objs = [r[0] for r in results]
     if force or any(r[1] for r in results) or not os.path.exists(LIB):
-        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + \
+        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-Wl,-soname,libnfft_hip.so", "-o", LIB] + objs + \
               ["-L" + os.path.join(ROCM, "lib"), "-lrocfft", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
         subprocess.check_call(cmd)
         if verbose:
             print("built", LIB)
+    build_core(force, hdr, verbose)
     return LIB
+
+
+def build_core(force=False, hdr_mtime=0.0, verbose=True):
+    """core.so: the TORCH_LIBRARY operator registry (host C++ only) linked against libnfft_hip.so."""
+    newest = max(os.path.getmtime(CORE_SRC), os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "nfft_hip.h")))
+    if not force and os.path.exists(CORE) and os.path.getmtime(CORE) >= newest:
+        return CORE
+    import torch
+    from torch.utils import cpp_extension as ce
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unknown-pragmas",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DHIPBLAS_V2",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    cmd += ["-isystem" + p for p in ce.include_paths()] + ["-isystem" + os.path.join(ROCM, "include")]
+    cmd += [CORE_SRC, "-o", CORE, "-L" + HERE, "-lnfft_hip", "-L" + tlib, "-lc10", "-lc10_hip", "-ltorch_cpu",
+            "-ltorch_hip", "-ltorch", "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
+    subprocess.check_call(cmd)
+    if verbose:
+        print("built", CORE)
+    return CORE
 
 
 if __name__ == "__main__":

@@ -10,7 +10,9 @@
 //   * the preconditions the reference only documents (1 <= m, 2m+2 <= 2N, N even) are checked.
 #include "../../include/nfft_hip.h"
 
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -24,7 +26,8 @@ void set_error(const std::string &msg) { g_last_error = msg; }
 // ---- optional stage timing -------------------------------------------------------------------
 namespace {
 struct TimedSpan { int stage; hipEvent_t start, stop; };
-bool g_profile = false;
+std::atomic<bool> g_profile{false};
+std::mutex g_spans_mutex;  // guards g_spans / g_free_events (the entry points may be called from several threads)
 std::vector<TimedSpan> g_spans;
 std::vector<hipEvent_t> g_free_events;
 hipEvent_t get_event()
@@ -38,7 +41,8 @@ hipEvent_t get_event()
 
 StageTimer::StageTimer(Stage stage, hipStream_t s) : slot(-1), stream(s)
 {
-    if (!g_profile) return;
+    if (!g_profile.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lock(g_spans_mutex);
     TimedSpan sp{(int)stage, get_event(), get_event()};
     (void)hipEventRecord(sp.start, stream);
     slot = (int)g_spans.size();
@@ -46,19 +50,42 @@ StageTimer::StageTimer(Stage stage, hipStream_t s) : slot(-1), stream(s)
 }
 StageTimer::~StageTimer()
 {
-    if (slot >= 0) (void)hipEventRecord(g_spans[slot].stop, stream);
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lock(g_spans_mutex);
+    if (slot < (int)g_spans.size()) (void)hipEventRecord(g_spans[slot].stop, stream);
 }
 
+int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev;
+}
+
+// CU count of the CURRENT device (cached per device: a process may drive several)
 int device_cu_count()
 {
-    static const int ncu = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-            v = 256;
-        return v;
-    }();
-    return ncu;
+    static std::atomic<int> cache[kMaxDevices];
+    const int dev = current_device();
+    if (dev >= kMaxDevices) return 256;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v <= 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cache[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+bool DeviceOnce::first_use()
+{
+    const int dev = current_device();
+    if (dev >= kMaxDevices) return true;
+    return !done[dev].load(std::memory_order_acquire);
+}
+void DeviceOnce::mark()
+{
+    const int dev = current_device();
+    if (dev < kMaxDevices) done[dev].store(true, std::memory_order_release);
 }
 
 SpreadMode spread_mode()
@@ -226,12 +253,13 @@ const char *nfft_hip_last_error(void) { return g_last_error.c_str(); }
 
 void nfft_hip_profile_enable(int enable)
 {
-    g_profile = enable != 0;
+    g_profile.store(enable != 0);
 }
 
 int nfft_hip_profile_collect(double *ms_per_stage, int64_t *launches_per_stage, int num_stages)
 {
     for (int i = 0; i < num_stages; ++i) { ms_per_stage[i] = 0.0; launches_per_stage[i] = 0; }
+    std::lock_guard<std::mutex> lock(g_spans_mutex);
     for (const TimedSpan &sp : g_spans) {
         float ms = 0.f;
         NFFT_HIP_CHECK(hipEventSynchronize(sp.stop));
@@ -307,7 +335,7 @@ int nfft_hip_interpolate(const nfft_hip_problem *p, const void *plan, const floa
 
 static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64_t *batch, const void *ext_plan,
                         const void *x, int x_is_complex, int real_output, void *y, void *workspace,
-                        int64_t workspace_bytes, void *stream)
+                        int64_t workspace_bytes, void *stream, const void *mult = nullptr, int mult_kind = 0)
 {
     if (int rc = validate(p)) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -344,15 +372,15 @@ static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64
                 StageTimer t(kStageDeconv, s);
                 const int ppc_a = x_is_complex ? 2 : 1;
                 const int64_t K = c.g.N * (int64_t)c.g.N * c.g.N;
-                if (int rc = launch_colfft_adjoint(c.g, spec, own_rows, ws + c.off_col, c.chunk_planes, 1, x_is_complex, real_output, 0, np, grid, s)) return rc;
+                if (int rc = launch_colfft_adjoint(c.g, spec, own_rows, ws + c.off_col, c.chunk_planes, 1, x_is_complex, real_output, 0, np, grid, mult, mult_kind, s)) return rc;
                 if (int rc = launch_column_layout(true, grid, y, K, c.C, p0 / ppc_a, np / ppc_a, real_output ? 4 : 8, s)) return rc;
             } else {
                 StageTimer t(kStageDeconv, s);
-                if (int rc = launch_colfft_adjoint(c.g, spec, own_rows, ws + c.off_col, c.chunk_planes, c.C, x_is_complex, real_output, p0, np, y, s)) return rc;
+                if (int rc = launch_colfft_adjoint(c.g, spec, own_rows, ws + c.off_col, c.chunk_planes, c.C, x_is_complex, real_output, p0, np, y, mult, mult_kind, s)) return rc;
             }
         } else {
             { StageTimer t(kStageFft, s); if (int rc = fft_execute(kR2C, c.g.dim, c.g.M, np, grid, spec, work, c.work_bytes, s)) return rc; }
-            { StageTimer t(kStageDeconv, s); if (int rc = launch_deconv_adjoint(c.g, spec, c.C, x_is_complex, real_output, p0, np, y, s)) return rc; }
+            { StageTimer t(kStageDeconv, s); if (int rc = launch_deconv_adjoint(c.g, spec, c.C, x_is_complex, real_output, p0, np, y, mult, mult_kind, s)) return rc; }
         }
     }
     return 0;
@@ -432,6 +460,118 @@ int nfft_hip_forward_planned(const nfft_hip_problem *p, const void *plan, const 
 {
     if (!plan) { set_error("Input mismatch: plan is null"); return NFFT_HIP_EINVAL; }
     return forward_impl(p, nullptr, nullptr, plan, xhat, x_is_complex, real_output, y, workspace, workspace_bytes, stream);
+}
+
+// ---- fast summation -------------------------------------------------------------------------
+namespace {
+struct FastsumCarve {
+    int64_t band_bytes, plan_s, plan_t, inner, off_band, off_plan_s, off_plan_t, off_inner, total;
+};
+int fastsum_check(const nfft_hip_problem *src, const nfft_hip_problem *tgt)
+{
+    if (int rc = validate(src)) return rc;
+    if (int rc = validate(tgt)) return rc;
+    if (src->dim != tgt->dim || src->N != tgt->N || src->m != tgt->m || src->batch_size != tgt->batch_size ||
+        src->num_columns != tgt->num_columns) {
+        set_error("Input mismatch: sources and targets disagree in dim / N / m / batch size / columns");
+        return NFFT_HIP_EINVAL;
+    }
+    return 0;
+}
+int fastsum_carve(const nfft_hip_problem *src, const nfft_hip_problem *tgt, int x_is_complex, bool own_plans,
+                  bool shared_points, FastsumCarve &f)
+{
+    Carve a, b;
+    if (int rc = make_carve(src, x_is_complex ? 2 : 1, true, kR2C, a)) return rc;
+    if (int rc = make_carve(tgt, x_is_complex ? 2 : 1, false, kC2R, b)) return rc;
+    int64_t band = src->batch_size * src->num_columns * 8;
+    for (int d = 0; d < src->dim; ++d) band *= src->N;
+    f.band_bytes = align_up(band, 256);
+    f.plan_s = own_plans ? align_up(a.L.total, 256) : 0;
+    f.plan_t = own_plans && !shared_points ? align_up(b.L.total, 256) : 0;
+    f.inner = std::max(a.total, b.total);
+    int64_t o = 0;
+    f.off_band = o;   o += f.band_bytes;
+    f.off_plan_s = o; o += f.plan_s;
+    f.off_plan_t = o; o += f.plan_t;
+    f.off_inner = o;  o += f.inner;
+    f.total = o + 256;
+    return 0;
+}
+int fastsum_impl(const nfft_hip_problem *src, const float *sources, const int64_t *source_batch, const void *source_plan,
+                 const nfft_hip_problem *tgt, const float *targets, const int64_t *target_batch, const void *target_plan,
+                 const void *x, int x_is_complex, const void *coeffs, int coeffs_are_complex, void *y, void *workspace,
+                 int64_t workspace_bytes, void *stream)
+{
+    if (int rc = fastsum_check(src, tgt)) return rc;
+    const bool own_plans = source_plan == nullptr;
+    const bool shared = own_plans ? (sources == targets && source_batch == target_batch && src->num_points == tgt->num_points)
+                                  : (source_plan == target_plan);
+    FastsumCarve f;
+    if (int rc = fastsum_carve(src, tgt, x_is_complex, own_plans, shared, f)) return rc;
+    if (tgt->num_points == 0 || src->num_columns == 0) return 0;
+    if (!coeffs || !y) { set_error("Input mismatch: null input"); return NFFT_HIP_EINVAL; }
+    if (!workspace || workspace_bytes < f.total) { set_error("workspace too small"); return NFFT_HIP_EWORKSPACE; }
+    char *ws = (char *)(((uintptr_t)workspace + 255) & ~uintptr_t(255));
+    hipStream_t s = (hipStream_t)stream;
+    if (own_plans) {
+        if (src->num_points > 0 && !sources) { set_error("Input mismatch: sources is null"); return NFFT_HIP_EINVAL; }
+        if (!targets) { set_error("Input mismatch: targets is null"); return NFFT_HIP_EINVAL; }
+        {
+            StageTimer t(kStagePlan, s);
+            const Geom g = make_geom(src->dim, src->N, src->m);
+            if (int rc = launch_plan_points(g, plan_layout(g, src->num_points, src->batch_size), sources, source_batch,
+                                            src->num_points, src->batch_size, ws + f.off_plan_s, s)) return rc;
+        }
+        source_plan = ws + f.off_plan_s;
+        target_plan = source_plan;
+        if (!shared) {
+            StageTimer t(kStagePlan, s);
+            const Geom g = make_geom(tgt->dim, tgt->N, tgt->m);
+            if (int rc = launch_plan_points(g, plan_layout(g, tgt->num_points, tgt->batch_size), targets, target_batch,
+                                            tgt->num_points, tgt->batch_size, ws + f.off_plan_t, s)) return rc;
+            target_plan = ws + f.off_plan_t;
+        }
+    }
+    void *band = ws + f.off_band;
+    if (src->num_points == 0) {
+        NFFT_HIP_CHECK(hipMemsetAsync(band, 0, (size_t)f.band_bytes, s));
+    } else {
+        // adjoint of the sources; the kernel's Fourier coefficients are multiplied in by the last spectral pass
+        if (int rc = adjoint_impl(src, nullptr, nullptr, source_plan, x, x_is_complex, 0, band, ws + f.off_inner, f.inner,
+                                  stream, coeffs, coeffs_are_complex ? 2 : 1)) return rc;
+    }
+    // forward transform at the targets; real coefficients give a real result (core_cuda.cu:817-821)
+    return forward_impl(tgt, nullptr, nullptr, target_plan, band, 1, x_is_complex ? 0 : 1, y, ws + f.off_inner, f.inner,
+                        stream);
+}
+} // namespace
+
+int64_t nfft_hip_fastsum_workspace_bytes(const nfft_hip_problem *src, const nfft_hip_problem *tgt, int x_is_complex,
+                                         int shared_points, int planned)
+{
+    if (fastsum_check(src, tgt)) return -1;
+    FastsumCarve f;
+    if (fastsum_carve(src, tgt, x_is_complex, planned == 0, shared_points != 0, f)) return -1;
+    return f.total;
+}
+
+int nfft_hip_fastsum(const nfft_hip_problem *src, const float *sources, const int64_t *source_batch,
+                     const nfft_hip_problem *tgt, const float *targets, const int64_t *target_batch, const void *x,
+                     int x_is_complex, const void *coeffs, int coeffs_are_complex, void *y, void *workspace,
+                     int64_t workspace_bytes, void *stream)
+{
+    return fastsum_impl(src, sources, source_batch, nullptr, tgt, targets, target_batch, nullptr, x, x_is_complex, coeffs,
+                        coeffs_are_complex, y, workspace, workspace_bytes, stream);
+}
+
+int nfft_hip_fastsum_planned(const nfft_hip_problem *src, const void *source_plan, const nfft_hip_problem *tgt,
+                             const void *target_plan, const void *x, int x_is_complex, const void *coeffs,
+                             int coeffs_are_complex, void *y, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (!source_plan || !target_plan) { set_error("Input mismatch: plan is null"); return NFFT_HIP_EINVAL; }
+    return fastsum_impl(src, nullptr, nullptr, source_plan, tgt, nullptr, nullptr, target_plan, x, x_is_complex, coeffs,
+                        coeffs_are_complex, y, workspace, workspace_bytes, stream);
 }
 
 } // extern "C"

@@ -235,13 +235,28 @@ adj_axis1_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__rest
     }
 }
 
+// fastsum: the kernel's Fourier coefficient of band frequency f rides along with the roll-off (1 real, 2 complex)
+__device__ __forceinline__ void apply_mult(const void *__restrict__ mult, int kind, int64_t f, float &re, float &im)
+{
+    if (kind == 1) {
+        const float w = ((const float *)mult)[f];
+        re *= w;
+        im *= w;
+    } else if (kind == 2) {
+        const float2 w = ((const float2 *)mult)[f];
+        const float r2 = re * w.x - im * w.y;
+        im = re * w.y + im * w.x;
+        re = r2;
+    }
+}
+
 // ---- adjoint, axis 0 + roll-off:  T -> y[b][N][N][N][C] ---------------------------------------------------
 // F = forward DFT of the real plane at (k0, k1, k2 >= 0).  g_hat (e^{+} convention) = conj(F); the k2 < 0 half
 // follows from g_hat[-k] = conj(g_hat[k]) = F[k].
 template <bool XCOMPLEX, bool REAL_OUT>
 __global__ void __launch_bounds__(kFftThreads)
 adj_axis0_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__restrict__ T, int64_t C, int64_t col0,
-                 void *__restrict__ yv)
+                 void *__restrict__ yv, const void *__restrict__ mult, int mult_kind)
 {
     extern __shared__ float2 smem[];
     float2 *ltw = smem;
@@ -286,17 +301,21 @@ adj_axis0_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__rest
         const float fac = phi_hat_inv_f(abs(k0), cg.param) * f1 * phi_hat_inv_f(k2, cg.param);
         if (k0 < H && k1 < H && k2 < H) {
             // direct: g_hat[k] = conj(F_re) + i conj(F_im)
-            const float re = fr.x + fi.y, im = -fr.y + fi.x;
-            const int64_t o = ((((b * N + (k0 + H)) * N + (k1 + H)) * N + (k2 + H)) * C) + c;
-            if (REAL_OUT) ((float *)yv)[o] = re * fac;
-            else ((float2 *)yv)[o] = make_float2(re * fac, im * fac);
+            float re = (fr.x + fi.y) * fac, im = (-fr.y + fi.x) * fac;
+            const int64_t f = ((int64_t)(k0 + H) * N + (k1 + H)) * N + (k2 + H);
+            apply_mult(mult, mult_kind, f, re, im);
+            const int64_t o = (b * N * N * N + f) * C + c;
+            if (REAL_OUT) ((float *)yv)[o] = re;
+            else ((float2 *)yv)[o] = make_float2(re, im);
         }
         if (k2 >= 1 && k0 > -H && k1 > -H) {
             // mirror: g_hat[-k] = F_re + i F_im
-            const float re = fr.x - fi.y, im = fr.y + fi.x;
-            const int64_t o = ((((b * N + (H - k0)) * N + (H - k1)) * N + (H - k2)) * C) + c;
-            if (REAL_OUT) ((float *)yv)[o] = re * fac;
-            else ((float2 *)yv)[o] = make_float2(re * fac, im * fac);
+            float re = (fr.x - fi.y) * fac, im = (fr.y + fi.x) * fac;
+            const int64_t f = ((int64_t)(H - k0) * N + (H - k1)) * N + (H - k2);
+            apply_mult(mult, mult_kind, f, re, im);
+            const int64_t o = (b * N * N * N + f) * C + c;
+            if (REAL_OUT) ((float *)yv)[o] = re;
+            else ((float2 *)yv)[o] = make_float2(re, im);
         }
     }
 }
@@ -690,7 +709,7 @@ static float2 *twiddle_ptr(const Geom &g, int64_t nplanes, void *scratch)
 
 int launch_colfft_adjoint(const Geom &g, const float2 *spec, bool compact, void *scratch, int64_t scratch_planes,
                           int64_t C, int x_is_complex, int real_output, int64_t plane0, int64_t nplanes, void *y,
-                          hipStream_t stream)
+                          const void *mult, int mult_kind, hipStream_t stream)
 {
     if (nplanes <= 0) return 0;
     float2 *T = (float2 *)scratch;
@@ -714,11 +733,11 @@ int launch_colfft_adjoint(const Geom &g, const float2 *spec, bool compact, void 
         allow_lds(adj_axis0_kernel<false, true>, lds);
         allow_lds(adj_axis0_kernel<false, false>, lds);
         if (two) {
-            if (real_output) hipLaunchKernelGGL((adj_axis0_kernel<true, true>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, C, col0, y);
-            else hipLaunchKernelGGL((adj_axis0_kernel<true, false>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, C, col0, y);
+            if (real_output) hipLaunchKernelGGL((adj_axis0_kernel<true, true>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, C, col0, y, mult, mult_kind);
+            else hipLaunchKernelGGL((adj_axis0_kernel<true, false>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, C, col0, y, mult, mult_kind);
         } else {
-            if (real_output) hipLaunchKernelGGL((adj_axis0_kernel<false, true>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, C, col0, y);
-            else hipLaunchKernelGGL((adj_axis0_kernel<false, false>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, C, col0, y);
+            if (real_output) hipLaunchKernelGGL((adj_axis0_kernel<false, true>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, C, col0, y, mult, mult_kind);
+            else hipLaunchKernelGGL((adj_axis0_kernel<false, false>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, C, col0, y, mult, mult_kind);
         }
     }
     NFFT_HIP_CHECK(hipGetLastError());

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <string>
 
 namespace nfft {
@@ -231,7 +232,16 @@ inline int seg_base_runs(int64_t n, int64_t nsets, int64_t pencils, int M, int n
     r = r < lo ? lo : (r > hi ? hi : r);
     return (int)(r > kSegMax ? kSegMax : r);
 }
-int device_cu_count();  // api.hip
+int device_cu_count();  // api.hip: CU count of the current device
+int current_device();
+// "done once per device" flag for per-kernel set-up (hipFuncSetAttribute is per device): a process may drive several
+// devices, so a plain static bool would skip the set-up on every device but the first.
+constexpr int kMaxDevices = 64;
+struct DeviceOnce {
+    std::atomic<bool> done[kMaxDevices];
+    bool first_use();
+    void mark();
+};
 
 struct PlanLayout {
     int64_t ntiles;

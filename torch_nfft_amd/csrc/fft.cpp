@@ -4,11 +4,14 @@
 // (csrc/cuda/core_cuda.cu:254-272, 432-450).  The reference transforms a complex (2N)^d grid per
 // (batch, column); here every grid plane is real, so the adjoint uses a real-to-complex transform and
 // the forward a complex-to-real one (half the data and work), batched over the planes of a chunk.
-// Plans are created once per (kind, dim, M, batch, device) and kept; execution is bound to the
-// caller's stream (the reference leaves cuFFT on the default stream and synchronises the device).
+// Plans are created once per (kind, dim, M, batch, device) and kept in a bounded least-recently-used cache
+// (kMaxPlans entries: workloads whose number of point sets varies from call to call would otherwise grow it
+// without limit); execution is bound to the caller's stream (the reference leaves cuFFT on the default stream
+// and synchronises the device).
 #include <rocfft/rocfft.h>
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <tuple>
 
@@ -18,11 +21,15 @@ namespace nfft {
 
 namespace {
 struct PlanEntry {
-    rocfft_plan plan = nullptr;
+    // shared ownership: an entry evicted from the cache stays alive until the call that is executing it returns
+    std::shared_ptr<rocfft_plan_t> plan;
     size_t work_bytes = 0;
+    uint64_t last_use = 0;
 };
+constexpr size_t kMaxPlans = 32;
 std::mutex g_mutex;
 bool g_setup = false;
+uint64_t g_tick = 0;
 std::map<std::tuple<int, int, int, int, int64_t>, PlanEntry> g_plans;
 
 const char *status_name(rocfft_status s)
@@ -56,6 +63,7 @@ int get_plan(FftKind kind, int dim, int M, int64_t nplanes, PlanEntry &out)
     const auto key = std::make_tuple(dev, (int)kind, dim, M, nplanes);
     auto it = g_plans.find(key);
     if (it != g_plans.end()) {
+        it->second.last_use = ++g_tick;
         out = it->second;
         return 0;
     }
@@ -67,21 +75,30 @@ int get_plan(FftKind kind, int dim, int M, int64_t nplanes, PlanEntry &out)
     if (rows)  // one 1-D transform per grid row: planes * M^(dim-1) rows
         for (int a = 1; a < dim; ++a) batch *= (size_t)M;
     rocfft_status st;
+    rocfft_plan raw = nullptr;
     if (kind == kC2CForward)
-        st = rocfft_plan_create(&e.plan, rocfft_placement_inplace, rocfft_transform_type_complex_forward,
+        st = rocfft_plan_create(&raw, rocfft_placement_inplace, rocfft_transform_type_complex_forward,
                                 rocfft_precision_single, (size_t)dim, lengths, batch, nullptr);
     else
-        st = rocfft_plan_create(&e.plan, rocfft_placement_notinplace,
+        st = rocfft_plan_create(&raw, rocfft_placement_notinplace,
                                 fwd ? rocfft_transform_type_real_forward : rocfft_transform_type_real_inverse,
                                 rocfft_precision_single, rows ? 1 : (size_t)dim, lengths, batch, nullptr);
     if (st != rocfft_status_success) {
         set_error(std::string("Failed to create rocFFT plan: ") + status_name(st));
         return 3;
     }
-    st = rocfft_plan_get_work_buffer_size(e.plan, &e.work_bytes);
+    e.plan = std::shared_ptr<rocfft_plan_t>(raw, [](rocfft_plan_t *p) { rocfft_plan_destroy(p); });
+    st = rocfft_plan_get_work_buffer_size(raw, &e.work_bytes);
     if (st != rocfft_status_success) {
         set_error(std::string("rocfft_plan_get_work_buffer_size: ") + status_name(st));
         return 3;
+    }
+    e.last_use = ++g_tick;
+    if (g_plans.size() >= kMaxPlans) {
+        auto victim = g_plans.begin();
+        for (auto jt = g_plans.begin(); jt != g_plans.end(); ++jt)
+            if (jt->second.last_use < victim->second.last_use) victim = jt;
+        g_plans.erase(victim);
     }
     g_plans[key] = e;
     out = e;
@@ -112,7 +129,7 @@ int fft_execute(FftKind kind, int dim, int M, int64_t nplanes, void *in, void *o
         st = rocfft_execution_info_set_work_buffer(info, work, e.work_bytes);
     void *ins[1] = {in};
     void *outs[1] = {out};
-    if (st == rocfft_status_success) st = rocfft_execute(e.plan, ins, outs, info);
+    if (st == rocfft_status_success) st = rocfft_execute(e.plan.get(), ins, outs, info);
     if (info) rocfft_execution_info_destroy(info);
     if (st != rocfft_status_success) {
         set_error(std::string("Failed to execute rocFFT plan: ") + status_name(st));

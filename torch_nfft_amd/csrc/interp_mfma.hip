@@ -272,13 +272,13 @@ static int launch_gm_t(const Geom &g, const PlanLayout &L, const void *plan, con
     const int nsegm = seg_base_runs(n, nsets, pencils, g.M, device_cu_count());
     const int seg_slabs = (g.M + nsegm - 1) / nsegm;
     const dim3 blocks((unsigned)(pencils * nsegm), (unsigned)nplanes);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_done;
+    if (attr_done.first_use()) {
         NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)interp_mfma_kernel<W, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GatherMfmaLds)));
         NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)interp_mfma_kernel<W, true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GatherMfmaLds)));
-        attr_done = true;
+        attr_done.mark();
     }
     const char *base = (const char *)plan;
     const int *first_end = (const int *)(base + L.off_cursor);

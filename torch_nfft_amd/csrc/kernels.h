@@ -38,8 +38,9 @@ int launch_interp_mfma(const Geom &g, const PlanLayout &L, const void *plan, con
 
 // spectral.hip
 // adjoint roll-off: spec = R2C(grid) per real plane [nplanes, M^(d-1) * (M/2+1)] complex -> y [B, N^d, C]
+// mult / mult_kind: optional per-frequency factor [N^d] multiplied in on the way out (fastsum; 0 none, 1 float, 2 float2)
 int launch_deconv_adjoint(const Geom &g, const float2 *spec, int64_t C, int x_is_complex, int real_output,
-                          int64_t plane0, int64_t nplanes, void *y, hipStream_t stream);
+                          int64_t plane0, int64_t nplanes, void *y, const void *mult, int mult_kind, hipStream_t stream);
 // forward roll-off: xhat [B, N^d, C] -> Hermitian half-spectra of the real planes of g
 int launch_deconv_forward(const Geom &g, const void *xhat, int64_t C, int x_is_complex, int real_output,
                           int64_t plane0, int64_t nplanes, float2 *spec, hipStream_t stream);
@@ -60,7 +61,7 @@ int64_t colfft_scratch_bytes(const Geom &g, int64_t nplanes);
 // rocFFT's M/2+1
 int launch_colfft_adjoint(const Geom &g, const float2 *spec, bool compact, void *scratch, int64_t scratch_planes,
                           int64_t C, int x_is_complex, int real_output, int64_t plane0, int64_t nplanes, void *y,
-                          hipStream_t stream);
+                          const void *mult, int mult_kind, hipStream_t stream);
 int launch_colfft_forward(const Geom &g, const void *xhat, void *scratch, int64_t scratch_planes, int64_t C,
                           int x_is_complex, int real_output, int64_t plane0, int64_t nplanes, float2 *spec, bool compact,
                           hipStream_t stream);

@@ -49,7 +49,8 @@ __device__ __forceinline__ float phi_hat_inv(int k, float param) { return expf((
 // adjoint: one thread per (column, band frequency); i2 fastest so that spectrum reads are contiguous.
 template <bool XCOMPLEX, bool REAL_OUT>
 __global__ void __launch_bounds__(256) deconv_adjoint_kernel(SpecGeom s, const float2 *__restrict__ spec, int64_t C,
-                                                            int64_t col0, int64_t ncols, void *__restrict__ yv)
+                                                            int64_t col0, int64_t ncols, void *__restrict__ yv,
+                                                            const void *__restrict__ mult, int mult_kind)
 {
     const int64_t total = ncols * s.band;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -89,10 +90,23 @@ __global__ void __launch_bounds__(256) deconv_adjoint_kernel(SpecGeom s, const f
             re = fr.x;
             im = conj ? -fr.y : fr.y;
         }
+        re *= fac;
+        im *= fac;
+        // fastsum: the kernel's Fourier coefficient of this frequency rides along (mult_kind 1 real, 2 complex)
+        if (mult_kind == 1) {
+            const float w = ((const float *)mult)[fidx];
+            re *= w;
+            im *= w;
+        } else if (mult_kind == 2) {
+            const float2 w = ((const float2 *)mult)[fidx];
+            const float r2 = re * w.x - im * w.y;
+            im = re * w.y + im * w.x;
+            re = r2;
+        }
         if (REAL_OUT) {
-            ((float *)yv)[oidx] = re * fac;
+            ((float *)yv)[oidx] = re;
         } else {
-            ((float2 *)yv)[oidx] = make_float2(re * fac, im * fac);
+            ((float2 *)yv)[oidx] = make_float2(re, im);
         }
     }
 }
@@ -167,7 +181,7 @@ static inline int grid_for(int64_t work, int block)
 }
 
 int launch_deconv_adjoint(const Geom &g, const float2 *spec, int64_t C, int x_is_complex, int real_output,
-                          int64_t plane0, int64_t nplanes, void *y, hipStream_t stream)
+                          int64_t plane0, int64_t nplanes, void *y, const void *mult, int mult_kind, hipStream_t stream)
 {
     const SpecGeom s = make_spec_geom(g);
     const int ppc = x_is_complex ? 2 : 1;
@@ -175,11 +189,11 @@ int launch_deconv_adjoint(const Geom &g, const float2 *spec, int64_t C, int x_is
     if (ncols <= 0) return 0;
     const dim3 grid(grid_for(ncols * s.band, 256)), block(256);
     if (x_is_complex) {
-        if (real_output) hipLaunchKernelGGL((deconv_adjoint_kernel<true, true>), grid, block, 0, stream, s, spec, C, col0, ncols, y);
-        else hipLaunchKernelGGL((deconv_adjoint_kernel<true, false>), grid, block, 0, stream, s, spec, C, col0, ncols, y);
+        if (real_output) hipLaunchKernelGGL((deconv_adjoint_kernel<true, true>), grid, block, 0, stream, s, spec, C, col0, ncols, y, mult, mult_kind);
+        else hipLaunchKernelGGL((deconv_adjoint_kernel<true, false>), grid, block, 0, stream, s, spec, C, col0, ncols, y, mult, mult_kind);
     } else {
-        if (real_output) hipLaunchKernelGGL((deconv_adjoint_kernel<false, true>), grid, block, 0, stream, s, spec, C, col0, ncols, y);
-        else hipLaunchKernelGGL((deconv_adjoint_kernel<false, false>), grid, block, 0, stream, s, spec, C, col0, ncols, y);
+        if (real_output) hipLaunchKernelGGL((deconv_adjoint_kernel<false, true>), grid, block, 0, stream, s, spec, C, col0, ncols, y, mult, mult_kind);
+        else hipLaunchKernelGGL((deconv_adjoint_kernel<false, false>), grid, block, 0, stream, s, spec, C, col0, ncols, y, mult, mult_kind);
     }
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;

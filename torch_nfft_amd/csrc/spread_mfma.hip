@@ -415,13 +415,13 @@ static int launch_mfma_t(const Geom &g, const PlanLayout &L, const void *plan, c
     const int nsegm = seg_base_runs(n, nsets, pencils, g.M, device_cu_count());
     const int seg_slabs = (g.M + nsegm - 1) / nsegm;
     const dim3 blocks((unsigned)(pencils * nsegm), (unsigned)nplanes);
-    static bool attr_done = false;  // one workgroup per CU: the double-buffered operands take most of the 160 KB LDS
-    if (!attr_done) {
+    static DeviceOnce attr_done;  // one workgroup per CU: the double-buffered operands take most of the 160 KB LDS
+    if (attr_done.first_use()) {
         NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)spread_mfma_kernel<W, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MfmaLds<W>)));
         NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)spread_mfma_kernel<W, true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MfmaLds<W>)));
-        attr_done = true;
+        attr_done.mark();
     }
     const char *base = (const char *)plan;
     const int *first_end = (const int *)(base + L.off_cursor);

@@ -9,7 +9,9 @@ reduction; the only exchange is an optional all-gather of the per-rank results w
 the full result on every rank (``gather=True``).  A call with a single point set is not split (that
 would need a distributed FFT): it runs on the rank that owns batch 0.
 
-Rank r of R takes the point sets [floor(r B / R), floor((r+1) B / R)).
+Rank r of R takes the point sets [floor(r B / R), floor((r+1) B / R)).  ``shard_adjoint`` / ``shard_forward``
+compute one rank's share given (rank, world) explicitly -- the sharded calls are these plus the all-gather, and
+a single process can run every shard of a simulated world one after the other (tests, one-GPU rehearsal).
 """
 import torch
 import torch.distributed as dist
@@ -60,17 +62,13 @@ def _all_gather_rows(local, sizes, group):
     return torch.cat([out[r * smax:r * smax + sizes[r]] for r in range(world)], dim=0)
 
 
-def nfft_adjoint(x, pos, batch=None, bandwidth=16, cutoff=3, real_output=False, group=None, gather=True,
-                 local_op=None):
-    """Sharded ``nfft_adjoint``.  ``x``, ``pos``, ``batch`` describe the WHOLE batch and are present on every
-    rank; each rank transforms its own point sets.  Returns the full ``[B, N.., *cols]`` spectrum on every
-    rank (``gather=True``, one all-gather along dim 0) or this rank's ``[B_r, N.., *cols]`` slab."""
+def shard_adjoint(x, pos, batch, batch_size, rank, world, bandwidth=16, cutoff=3, real_output=False, local_op=None,
+                  bounds=None):
+    """The slab ``[B_r, N.., *cols]`` of the adjoint transform that rank ``rank`` of ``world`` owns."""
     op = local_op or _nfft.nfft_adjoint
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    B = _batch_size(batch)
-    bounds = point_bounds(batch, B, world, pos.shape[0])
-    b0, b1 = batch_range(B, rank, world)
+    if bounds is None:
+        bounds = point_bounds(batch, batch_size, world, pos.shape[0])
+    b0, b1 = batch_range(batch_size, rank, world)
     i0, i1 = bounds[rank], bounds[rank + 1]
     if b1 > b0:
         lb = None if batch is None else batch[i0:i1] - b0
@@ -81,10 +79,42 @@ def nfft_adjoint(x, pos, batch=None, bandwidth=16, cutoff=3, real_output=False, 
             pad = y.new_zeros((b1 - b0,) + tuple(y.shape[1:]))
             pad[:y.shape[0]] = y
             y = pad
-    else:
-        d = pos.shape[1]
-        y = x.new_zeros((0,) + (bandwidth,) * d + tuple(x.shape[1:]),
-                        dtype=torch.float32 if real_output else torch.complex64)
+        return y
+    d = pos.shape[1]
+    return x.new_zeros((0,) + (bandwidth,) * d + tuple(x.shape[1:]),
+                       dtype=torch.float32 if real_output else torch.complex64)
+
+
+def shard_forward(x, pos, batch, batch_size, rank, world, cutoff=3, real_output=False, local_op=None, bounds=None):
+    """The rows ``[n_r, *cols]`` of the forward transform that rank ``rank`` of ``world`` owns (``x`` is the full
+    ``[B, N.., *cols]`` spectrum; only the rank's own slab is read)."""
+    op = local_op or _nfft.nfft_forward
+    d = pos.shape[1]
+    if bounds is None:
+        bounds = point_bounds(batch, batch_size, world, pos.shape[0])
+    b0, _ = batch_range(batch_size, rank, world)
+    i0, i1 = bounds[rank], bounds[rank + 1]
+    if i1 > i0:
+        lb = None if batch is None else batch[i0:i1] - b0
+        nb = 1 if lb is None else int(lb[-1].item()) + 1  # the shard's last point sets may be empty
+        return op(x[b0:b0 + nb], pos[i0:i1], lb, cutoff=cutoff, real_output=real_output)
+    return x.new_zeros((0,) + tuple(x.shape[1 + d:]), dtype=torch.float32 if real_output else torch.complex64)
+
+
+def _world(group):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def nfft_adjoint(x, pos, batch=None, bandwidth=16, cutoff=3, real_output=False, group=None, gather=True,
+                 local_op=None):
+    """Sharded ``nfft_adjoint``.  ``x``, ``pos``, ``batch`` describe the WHOLE batch and are present on every
+    rank; each rank transforms its own point sets.  Returns the full ``[B, N.., *cols]`` spectrum on every
+    rank (``gather=True``, one all-gather along dim 0) or this rank's ``[B_r, N.., *cols]`` slab."""
+    rank, world = _world(group)
+    B = _batch_size(batch)
+    y = shard_adjoint(x, pos, batch, B, rank, world, bandwidth, cutoff, real_output, local_op)
     if not gather or world == 1:
         return y
     sizes = [batch_range(B, r, world)[1] - batch_range(B, r, world)[0] for r in range(world)]
@@ -94,23 +124,12 @@ def nfft_adjoint(x, pos, batch=None, bandwidth=16, cutoff=3, real_output=False, 
 def nfft_forward(x, pos, batch=None, cutoff=3, real_output=False, group=None, gather=True, local_op=None):
     """Sharded ``nfft_forward``.  ``x`` is the full ``[B, N.., *cols]`` spectrum (each rank only reads its own
     slab); returns all ``[n, *cols]`` rows on every rank (``gather=True``) or this rank's rows."""
-    op = local_op or _nfft.nfft_forward
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    rank, world = _world(group)
     B = _batch_size(batch)
     if x.shape[0] != B:
         raise RuntimeError("Input mismatch")
-    d = pos.shape[1]
     bounds = point_bounds(batch, B, world, pos.shape[0])
-    b0, b1 = batch_range(B, rank, world)
-    i0, i1 = bounds[rank], bounds[rank + 1]
-    cols = tuple(x.shape[1 + d:])
-    if i1 > i0:
-        lb = None if batch is None else batch[i0:i1] - b0
-        nb = 1 if lb is None else int(lb[-1].item()) + 1  # the shard's last point sets may be empty
-        y = op(x[b0:b0 + nb], pos[i0:i1], lb, cutoff=cutoff, real_output=real_output)
-    else:
-        y = x.new_zeros((0,) + cols, dtype=torch.float32 if real_output else torch.complex64)
+    y = shard_forward(x, pos, batch, B, rank, world, cutoff, real_output, local_op, bounds)
     if not gather or world == 1:
         return y
     sizes = [bounds[r + 1] - bounds[r] for r in range(world)]

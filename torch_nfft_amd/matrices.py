@@ -1,73 +1,96 @@
-"""Matrix-free linear operators on top of ``nfft_fastsum`` (reference: ``torch_nfft/matrices.py``).
+"""Matrix-free kernel matrices on top of ``nfft_fastsum``: the public classes of the reference's
+``torch_nfft/matrices.py`` (``GramMatrix``, ``AdjacencyMatrix``; same constructor arguments, ``@`` / ``.T`` /
+``row_sums`` / ``column_sums`` / ``to_dense`` / ``is_symmetric``), written from the operator algebra:
 
-Same classes, methods and defaults.  Two defects of the reference are not reproduced: ``GramMatrix.is_symmetric``
-compares ``sources`` with itself (matrices.py:65) and ``AdjacencyMatrix.apply_shift`` reads an undefined name
-(matrices.py:149)."""
+    Gram       K x        with K[i, j] = kernel(source_j - target_i), one fastsum per product
+    adjacency  A = L (K + c I) R     with diagonal L, R chosen by the normalisation
+               y = A x                         no shift
+               y = S x - A x   /   S x + A x   Laplacian / signless Laplacian, S = D (unnormalised) or I (normalised)
+
+where D = diag((K + c I) 1) are the node degrees.  Normalisations: "sym" L = R = D^-1/2; "left" (alias "rw")
+L = D^-1; "right" R = D^-1.  The transpose of an adjacency operator swaps L and R and keeps everything else, so it
+is built from the parts without another degree computation.
+
+Two defects of the reference are not reproduced: its ``GramMatrix.is_symmetric`` compares ``sources`` with itself
+(matrices.py:65) and its shift step reads an undefined name (matrices.py:149).
+"""
 import warnings
 
 import torch
 
 from .nfft import nfft_fastsum
 
+_NORMALIZATIONS = {"none": "none", "sym": "sym", "left": "left", "rw": "left", "right": "right"}
+_SHIFT_SIGN = {"none": 0, "laplacian": -1, "signless": +1}
+
+
+def _scale_rows(diag, x):
+    """diag(diag) @ x for x of shape [n, *cols]; ``diag`` None is the identity."""
+    if diag is None:
+        return x
+    return diag.reshape((-1,) + (1,) * (x.dim() - 1)) * x
+
 
 class AbstractMatrix:
+    """A linear map given by its action ``apply`` on ``[n_in, *cols]`` tensors.  ``shape`` follows the reference:
+    ``(number of sources, number of targets)`` = (input length, output length)."""
+
     def __init__(self, shape, device):
-        self.shape = shape
+        self.shape = tuple(shape)
         self.device = device
 
+    # -- to be provided by subclasses
     def apply(self, x):
         raise NotImplementedError()
-
-    def __matmul__(self, x):
-        return self.apply(x)
 
     def is_symmetric(self):
         return False
 
     def transpose(self):
-        if self.is_symmetric():
-            return self
-        raise NotImplementedError()
+        if not self.is_symmetric():
+            raise NotImplementedError()
+        return self
+
+    # -- derived
+    def __matmul__(self, x):
+        return self.apply(x)
 
     @property
     def T(self):
         return self.transpose()
 
+    def _probe(self, make):
+        return self.apply(make(self.shape[0], device=self.device))
+
     def row_sums(self):
-        # the operator maps R^(#sources) -> R^(#targets); shape follows the reference: (sources, targets)
-        return self.apply(torch.ones(self.shape[0], device=self.device))
+        return self._probe(torch.ones)
 
     def column_sums(self):
-        return self.T.row_sums()
+        return self.transpose().row_sums()
 
     def to_dense(self):
-        return self.apply(torch.eye(self.shape[0], device=self.device))
+        return self._probe(torch.eye)
 
 
 class GramMatrix(AbstractMatrix):
-    """K[i, j] = kernel(source_j - target_i), applied with nfft_fastsum (matrices.py:41-69)."""
-
     def __init__(self, coeffs, sources, targets=None, source_batch=None, target_batch=None, /, batch=None, cutoff=3):
+        if batch is not None:
+            source_batch, target_batch = batch, batch
+        elif targets is None:
+            target_batch = source_batch
         if targets is None:
             targets = sources
-            target_batch = source_batch
-        if batch is not None:
-            source_batch = batch
-            target_batch = batch
-        super().__init__((sources.size(0), targets.size(0)), sources.device)
-        self.coeffs = coeffs
-        self.sources = sources
-        self.targets = targets
-        self.source_batch = source_batch
-        self.target_batch = target_batch
-        self.cutoff = cutoff
+        self.coeffs, self.cutoff = coeffs, cutoff
+        self.sources, self.source_batch = sources, source_batch
+        self.targets, self.target_batch = targets, target_batch
+        super().__init__((sources.shape[0], targets.shape[0]), sources.device)
 
     def apply(self, x):
         return nfft_fastsum(x, self.coeffs, self.sources, self.targets, self.source_batch, self.target_batch,
                             cutoff=self.cutoff)
 
     def is_symmetric(self):
-        return self.sources is self.targets and self.source_batch is self.target_batch
+        return self.targets is self.sources and self.target_batch is self.source_batch
 
     def transpose(self):
         if self.is_symmetric():
@@ -77,88 +100,68 @@ class GramMatrix(AbstractMatrix):
 
 
 class AdjacencyMatrix(AbstractMatrix):
-    """Graph adjacency operator W = K + offset*I of a symmetric Gram matrix with optional degree normalisation
-    ("sym", "left"/"rw", "right") and Laplacian / signless-Laplacian shift (matrices.py:73-175)."""
-
     def __init__(self, gram_matrix, diagonal_offset=0, normalization=None, shift=None, degree_threshold=0):
         if not gram_matrix.is_symmetric():
             raise ValueError("The underlying Gram matrix of an AdjacencyMatrix must be symmetric")
+        kind = "none" if normalization is None else str(normalization).lower()
+        if kind not in _NORMALIZATIONS:
+            raise ValueError(f"Unknown AdjacencyMatrix normalization type: {kind}")
+        kind = _NORMALIZATIONS[kind]
+        shift = "none" if shift is None else str(shift).lower()
+        if shift not in _SHIFT_SIGN:
+            raise ValueError(f"Unknown AdjacencyMatrix shift type: {shift}")
         super().__init__(gram_matrix.shape, gram_matrix.device)
         self.gram_matrix = gram_matrix
         self.diagonal_offset = diagonal_offset
-        normalization = "none" if normalization is None else normalization.lower()
-        if normalization == "rw":
-            normalization = "left"
-        if normalization not in ("none", "sym", "left", "right"):
-            raise ValueError(f"Unknown AdjacencyMatrix normalization type: {normalization}")
-        self.normalization = normalization
-        shift = "none" if shift is None else shift.lower()
-        if shift not in ("none", "laplacian", "signless"):
-            raise ValueError(f"Unknown AdjacencyMatrix shift type: {shift}")
+        self.normalization = kind
         self.shift = shift
+        self._left = self._right = self._shift_diag = None  # None = identity
+        if kind == "none" and shift == "none":
+            return
+        degrees = gram_matrix.row_sums() + diagonal_offset
+        if kind == "none":
+            self._shift_diag = degrees  # unnormalised (signless) Laplacian: D -+ W
+            return
+        isolated = degrees < degree_threshold
+        n_isolated = int(isolated.sum())
+        if n_isolated:
+            warnings.warn(f"AdjacencyMatrix with normalization: {n_isolated} out of {degrees.numel()} node degrees "
+                          f"are smaller than the threshold {degree_threshold:.4g}", RuntimeWarning, stacklevel=2)
+            degrees = torch.where(isolated, torch.full_like(degrees, float("inf")), degrees)  # their rows become 0
+        if kind == "sym":
+            self._left = self._right = degrees.rsqrt()
+        elif kind == "left":
+            self._left = degrees.reciprocal()
+        else:
+            self._right = degrees.reciprocal()
 
-        if shift != "none" or normalization != "none":
-            degrees = gram_matrix.row_sums()
-            if diagonal_offset != 0:
-                degrees = degrees + diagonal_offset
-            if normalization != "none":
-                small = degrees < degree_threshold
-                if torch.any(small):
-                    warnings.warn("AdjacencyMatrix with normalization: {} out of {} node degrees are smaller than "
-                                  "the threshold {:.4g}".format(int(small.sum()), degrees.numel(), degree_threshold),
-                                  RuntimeWarning, stacklevel=2)
-                    degrees = degrees.masked_fill(small, float("inf"))
-                if normalization == "sym":
-                    self.d_inv_sqrt = torch.rsqrt(degrees)
-                else:
-                    self.d_inv = 1 / degrees
-            else:
-                self.degrees = degrees
-
-    @staticmethod
-    def _rows(v, x):
-        return v[(...,) + (None,) * (x.dim() - 1)] * x
-
+    # names the reference exposes for the two scaling steps
     def apply_left_normalization(self, x):
-        if self.normalization == "sym":
-            return self._rows(self.d_inv_sqrt, x)
-        if self.normalization == "left":
-            return self._rows(self.d_inv, x)
-        return x
+        return _scale_rows(self._left, x)
 
     def apply_right_normalization(self, x):
-        if self.normalization == "sym":
-            return self._rows(self.d_inv_sqrt, x)
-        if self.normalization == "right":
-            return self._rows(self.d_inv, x)
-        return x
-
-    def apply_shift(self, x, y):
-        if self.shift == "none":
-            return y
-        if self.normalization == "none":
-            x = self._rows(self.degrees, x)
-        if self.shift == "signless":
-            return x + y
-        return x - y
+        return _scale_rows(self._right, x)
 
     def apply(self, x):
-        Dx = self.apply_right_normalization(x)
-        y = self.gram_matrix @ Dx
+        z = _scale_rows(self._right, x)
+        y = self.gram_matrix.apply(z)
         if self.diagonal_offset != 0:
-            y = y + self.diagonal_offset * Dx
-        y = self.apply_left_normalization(y)
-        return self.apply_shift(x, y)
+            y = y + self.diagonal_offset * z
+        y = _scale_rows(self._left, y)
+        sign = _SHIFT_SIGN[self.shift]
+        if sign == 0:
+            return y
+        base = _scale_rows(self._shift_diag, x)
+        return base + y if sign > 0 else base - y
 
     def is_symmetric(self):
-        return self.normalization not in ("left", "right")
+        return self._left is self._right  # both None, or the same D^-1/2
 
     def transpose(self):
-        if self.normalization in ("left", "right"):
-            # no normalization / shift arguments: they would trigger another degree computation
-            t = AdjacencyMatrix(self.gram_matrix, self.diagonal_offset, normalization=None, shift=None)
-            t.normalization = "right" if self.normalization == "left" else "left"
-            t.shift = self.shift
-            t.d_inv = self.d_inv
-            return t
-        return self
+        if self.is_symmetric():
+            return self
+        other = object.__new__(AdjacencyMatrix)
+        other.__dict__.update(self.__dict__)
+        other._left, other._right = self._right, self._left
+        other.normalization = "right" if self.normalization == "left" else "left"
+        return other

@@ -58,14 +58,11 @@ class NfftFastsumFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, coeffs, sources, targets, source_batch, target_batch, cutoff):
-        assert not coeffs.requires_grad, \
-            "NfftFastsum: Gradient computation w.r.t. coefficients is not possible"
-        assert not sources.requires_grad and not targets.requires_grad, \
-            "NfftFastsum: Gradient computation w.r.t. sources and targets is not possible"
-        assert source_batch is None or not source_batch.requires_grad, \
-            "NfftFastsum: Gradient computation w.r.t. batches is not possible"
-        assert target_batch is None or not target_batch.requires_grad, \
-            "NfftFastsum: Gradient computation w.r.t. batches is not possible"
+        # the operator is linear in x only: nothing else may ask for a gradient (reference: nfft.py:67-74)
+        for name, t in (("coeffs", coeffs), ("sources", sources), ("targets", targets),
+                        ("source_batch", source_batch), ("target_batch", target_batch)):
+            if t is not None and t.requires_grad:
+                raise AssertionError("nfft_fastsum is differentiable w.r.t. x only, but %s requires grad" % name)
         y = ops.nfft_fastsum(sources, targets, x, coeffs, source_batch, target_batch, cutoff)
         ctx.save_for_backward(sources, targets, coeffs, source_batch, target_batch)
         ctx.cutoff = cutoff
