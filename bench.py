@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
 """Benchmark of the NFFT hot path on MI355X (contract: see the task's bench.py section).
 
-Workload (BASELINE.json metric "Mpoints/s (adjoint+forward, 3-D N=256 m=4)"): config C3 -- d=3, N=256,
-m=4, n=10^7 uniform points, one point set, real fp32 coefficients.  One "step" = nfft_adjoint(x) followed
-by nfft_forward(of that spectrum, real_output=True), i.e. one pass of the hot path in each direction over
-one batch of synthetic input, inputs resident in HBM.  value = n_gpus * n / t_step / 1e6.
+Headline workload (BASELINE.json metric "Mpoints/s (adjoint+forward, 3-D N=256 m=4)"): config C3 -- d=3, N=256,
+m=4, n=10^7 uniform points, one point set, real fp32 coefficients.  One "step" = nfft_adjoint(x) followed by
+nfft_forward(of that spectrum, real_output=True), i.e. one pass of the hot path in each direction over one batch
+of synthetic input, inputs resident in HBM, the point plan rebuilt every step.  value = n_gpus * n / t_step / 1e6.
 
-N > 1 GPUs (launched by torch.distributed.run): every rank runs the same-sized workload on its own point
-set (the batch axis is the sharding axis of this path; a single point set cannot be split without a
-distributed FFT), no data-path collective, "scaling": "weak".
+The JSON line also carries, under "configs", one leg per other BASELINE.json configuration that fits one GPU
+(C1, C2, one GPU's share of C4, C5) and the clustered variant of C3, each with the median of
+>= 10 individually timed steps and its stage split -- parity cases first, timing legs second, never the headline.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a torch.distributed.run child
+process, spawned before this process touches the GPU); under a launcher (WORLD_SIZE set) it is one rank of the job.
+N > 1: every rank runs the C3 workload on its own point set (the batch axis is the sharding axis of this path; a
+single point set cannot be split without a distributed FFT), no data-path collective, "scaling": "weak"; plus the
+C4 leg sharded for real: `torch_nfft_amd.distributed` over B = 4 N point sets x 64 columns (B = 32 at N = 8, the
+configuration C4 names) with the RCCL all-gather of the per-rank spectra.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -26,33 +33,62 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_FMA_PER_S = 78.65e12      # 157.3 TFLOP/s fp32 vector = 78.65e12 FMA/s
 MFMA_F16_FLOPS = 2.5e15        # dense f16 matrix peak (MI355X_MICROARCH.md)
+ARITHMETIC = ("fp32 in / fp32 out; window sums on v_mfma_f32_32x32x16_f16 with two-way f16-split operands "
+              "(hi*hi + hi*lo + lo*hi, ~22 significant bits) and fp32 accumulation; FFT and roll-off in fp32")
+KERNEL_SOURCES = ("spread_mfma.hip", "spread_own.hip", "common.h", "mfma_split.h", "window.h")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--bandwidth", type=int, default=256)
     ap.add_argument("--cutoff", type=int, default=4)
     ap.add_argument("--dim", type=int, default=3)
     ap.add_argument("--dist", choices=["uniform", "clusters"], default="uniform",
-                    help="point distribution: uniform on the torus (the metric's workload) or 8 Gaussian clusters "
-                         "(sigma 0.05, SURVEY.md 8(d)'s robustness case)")
+                    help="point distribution of the headline workload: uniform on the torus (the metric's workload) "
+                         "or 8 Gaussian clusters (sigma 0.05, SURVEY.md 8(d)'s robustness case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the per-config legs (headline line only)")
+    ap.add_argument("--legs", default="c1,c2,c3clustered,c4share,c5", help="comma-separated legs to run at N=1")
+    ap.add_argument("--leg-reps", type=int, default=11, help="individually timed steps per leg (median reported)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
 
-def measured_traffic(d, N, m, n):
-    """HBM bytes per launch of the spreading kernel from the committed rocprofv3 PMC passes (FETCH_SIZE with the
-    gfx950 x2 correction + WRITE_SIZE; profiles/r01_v6_spread_traffic.json), if they were taken on this workload."""
+def self_launch(args):
+    """--gpus N > 1 outside a launcher: become the parent of a torch.distributed.run job.  Nothing in this process
+    has touched the GPU yet (torch is not even imported); the child's exit code is ours."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def kernel_source_hash():
+    h = hashlib.sha1()
+    for name in KERNEL_SOURCES:
+        path = os.path.join(ROOT, "torch_nfft_amd", "csrc", name)
+        if os.path.exists(path):
+            with open(path, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(kernel, workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE with the gfx950
+    x2 correction + WRITE_SIZE; written by scripts/pmc_traffic.py into profiles/).  Used only when the record was
+    taken for this kernel, this workload and THIS kernel source (hash of the kernel's source files): after any edit
+    of the kernel the figure is stale and the line says null until the PMC passes are re-run."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_v6_spread_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_spread_traffic.json")) as f:
             t = json.load(f)
-        w = t["workload"]
-        if (w["dim"], w["bandwidth"], w["cutoff"], w["points"]) == (d, N, m, n):
+        if t.get("kernel") == kernel and t.get("workload") == workload and t.get("source_hash") == kernel_source_hash():
             return t["fetch_bytes_corrected"] + t["write_bytes"]
     except (OSError, KeyError, ValueError):
         pass
@@ -62,6 +98,7 @@ def measured_traffic(d, N, m, n):
 def cpu_baseline(dim, N, target_s):
     """Oracle (this repo's restatement of torch_nfft/ndft.py, plain C + OpenMP) timed on the host cores on a
     bounded sample of the same workload: all N^dim frequencies, n' points (cost is linear in n')."""
+    import numpy as np
     from oracle import ndft_cpu
     cores = ndft_cpu.max_threads()
     rng = np.random.default_rng(20240)
@@ -92,6 +129,10 @@ def cpu_baseline(dim, N, target_s):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -104,21 +145,55 @@ def main():
     n_gpus = world
 
     import torch_nfft_amd as tn
-    from torch_nfft_amd import _lib
+    from torch_nfft_amd import _lib, ops
+    from torch_nfft_amd import distributed as tnd
 
-    d, N, m, n = args.dim, args.bandwidth, args.cutoff, args.points
-    M = 2 * N
-    gen = torch.Generator(device=dev).manual_seed(20240 + rank)
-    if args.dist == "uniform":
-        pos = torch.rand((n, d), generator=gen, device=dev) - 0.5
-    else:
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(v):
+        if not distributed:
+            return v
+        t = torch.tensor([v], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def make_points(n, d, kind, gen):
+        if kind == "uniform":
+            return torch.rand((n, d), generator=gen, device=dev) - 0.5
         centres = torch.rand((8, d), generator=gen, device=dev) - 0.5
         which = torch.randint(0, 8, (n,), generator=gen, device=dev)
         pos = centres[which] + 0.05 * torch.randn((n, d), generator=gen, device=dev)
-        pos = pos - torch.floor(pos + 0.5)  # back onto the torus
-    x = torch.rand((n,), generator=gen, device=dev)
+        return pos - torch.floor(pos + 0.5)  # back onto the torus
 
-    from torch_nfft_amd import ops
+    def timed_series(step, reps, warm=2):
+        """Median of `reps` individually synchronised steps + the per-stage GPU times (HIP events on the launch
+        stream) averaged per step."""
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize()
+        _lib.profile_enable(True)
+        _lib.profile_collect()
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        stages = _lib.profile_collect()
+        _lib.profile_enable(False)
+        ts.sort()
+        return ts[len(ts) // 2], ts[0], {k: v[0] / reps for k, v in stages.items() if v[1]}
+
+    # ------------------------------------------------------------------ headline: C3
+    d, N, m, n = args.dim, args.bandwidth, args.cutoff, args.points
+    M = 2 * N
+    gen = torch.Generator(device=dev).manual_seed(20240 + rank)
+    pos = make_points(n, d, args.dist, gen)
+    x = torch.rand((n,), generator=gen, device=dev)
 
     def step(fresh_plan=True):
         # One pass of the hot path in each direction over the same point set.  The point plan (tile binning) is
@@ -128,11 +203,6 @@ def main():
             ops.plan_cache_clear()
         y = tn.nfft_adjoint(x, pos, None, bandwidth=N, cutoff=m)
         return tn.nfft_forward(y, pos, None, cutoff=m, real_output=True)
-
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -146,27 +216,124 @@ def main():
     elapsed = time.perf_counter() - t0
     stages = _lib.profile_collect()
     _lib.profile_enable(False)
-    # secondary figure: the same steps with the point plan kept across steps (iterative use on fixed points)
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        step(fresh_plan=False)
-    barrier()
-    elapsed_cached = time.perf_counter() - t1
+    elapsed = max_over_ranks(elapsed)
+    # the same step timed one at a time (median of >= 10), and with the plan kept across steps
+    med_ms, min_ms, _ = timed_series(step, max(10, args.leg_reps), warm=0)
+    cached_ms, _, _ = timed_series(lambda: step(fresh_plan=False), max(10, args.leg_reps), warm=1)
 
+    legs = {}
+
+    def leg_adjoint_forward(name, workload, d_, N_, m_, pos_, x_, batch_, units, unit_name):
+        def st():
+            ops.plan_cache_clear()
+            y = tn.nfft_adjoint(x_, pos_, batch_, bandwidth=N_, cutoff=m_)
+            return tn.nfft_forward(y, pos_, batch_, cutoff=m_, real_output=True)
+        med, mn, per_stage = timed_series(st, args.leg_reps)
+        legs[name] = {"workload": workload, "ms_per_step_median": med, "ms_per_step_min": mn,
+                      "value": units / (med * 1e-3) / 1e6, "unit": unit_name, "stage_ms_per_step": per_stage}
+        return per_stage
+
+    want = set() if args.no_legs or distributed else set(s.strip() for s in args.legs.split(",") if s.strip())
+    g2 = torch.Generator(device=dev).manual_seed(777)
+    if "c1" in want:
+        p1 = make_points(1000, 1, "uniform", g2)
+        leg_adjoint_forward("C1", "1-D adjoint+forward, N=64, m=2, 1 000 uniform points, one point set (launch-latency "
+                            "bound: 1 KiB grid)", 1, 64, 2, p1, torch.rand((1000,), generator=g2, device=dev), None,
+                            1000, "Mpoints/s")
+        del p1
+    if "c2" in want:
+        p2 = make_points(100_000, 2, "uniform", g2)
+        leg_adjoint_forward("C2", "2-D adjoint+forward, N=128, m=4, 100 000 uniform points, batch_size=1", 2, 128, 4,
+                            p2, torch.rand((100_000,), generator=g2, device=dev), None, 100_000, "Mpoints/s")
+        del p2
+    if "c3clustered" in want and (d, N, m) == (3, 256, 4):
+        pc = make_points(n, 3, "clusters", g2)
+        leg_adjoint_forward("C3-clustered", "C3 with %d points in 8 Gaussian clusters (sigma 0.05) instead of uniform" % n,
+                            3, N, m, pc, x, None, n, "Mpoints/s")
+        del pc
+    if "c4share" in want:
+        B4, C4, n4 = 4, 64, 100_000
+        p4 = make_points(B4 * n4, 3, "uniform", g2)
+        b4 = torch.arange(B4 * n4, device=dev) // n4
+        x4 = torch.randn((B4 * n4, C4), generator=g2, device=dev)
+        st4 = leg_adjoint_forward("C4-share", "one GPU's share of C4 (B=32 over 8 GPUs): 3-D adjoint+forward, N=128, m=4, "
+                                  "4 point sets x 100 000 uniform points (assumed; BASELINE.json gives no n), 64 real "
+                                  "coefficient columns, forward with real_output", 3, 128, 4, p4, x4, b4,
+                                  B4 * n4 * C4, "M point-columns/s")
+        # here HBM does bind the spreading stage: every (set, column) grid of 256^3 floats is written once
+        alg4 = B4 * n4 * (4 * 3 + 4 * C4) + 8 * B4 * n4 + B4 * C4 * (256 ** 3) * 4
+        sp4 = st4.get("spread", 0.0) + st4.get("zero", 0.0)
+        if sp4 > 0:
+            legs["C4-share"]["roofline"] = {
+                "stage": "zero-fill + spreading (all kernels between the sorted points and the finished grids)",
+                "bound": "hbm", "algorithmic_bytes_per_step": alg4, "ms_per_step": sp4,
+                "achieved": alg4 / (sp4 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg4 / (sp4 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del p4, b4, x4
+    if "c5" in want:
+        n5 = 1_000_000
+        src = (torch.rand((n5, 3), generator=g2, device=dev) - 0.5) * 0.5  # radius-1/4 box (test_fastsum.py:17-18)
+        tgt = (torch.rand((n5, 3), generator=g2, device=dev) - 0.5) * 0.5
+        x5 = torch.rand((n5,), generator=g2, device=dev)
+        co = tn.gaussian_analytic_coeffs(0.1, dim=3, N=256)
+
+        def st5():
+            ops.plan_cache_clear()
+            return tn.nfft_fastsum(x5, co, src, tgt, cutoff=4)
+        med, mn, per_stage = timed_series(st5, args.leg_reps)
+        legs["C5"] = {"workload": "fastsum, Gaussian kernel sigma=0.1 (analytic coefficients), 10^6 sources x 10^6 "
+                                  "targets, 3-D N=256, m=4 (one native call, plans rebuilt every step)",
+                      "ms_per_step_median": med, "ms_per_step_min": mn, "value": (2 * n5) / (med * 1e-3) / 1e6,
+                      "unit": "Mpoints/s (sources + targets)", "stage_ms_per_step": per_stage}
+        del src, tgt, x5, co
+    torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ N > 1: C4 sharded for real (RCCL all-gather)
     if distributed:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        B4, C4, n4 = 4 * world, 64, 100_000
+        g4 = torch.Generator(device=dev).manual_seed(4242)  # same inputs on every rank: the wrapper's contract
+        p4 = torch.rand((B4 * n4, 3), generator=g4, device=dev) - 0.5
+        b4 = torch.arange(B4 * n4, device=dev) // n4
+        x4 = torch.randn((B4 * n4, C4), generator=g4, device=dev)
+        t_adj, t_gather, t_fwd, t_total = [], [], [], []
+        for it in range(2 + 5):
+            ops.plan_cache_clear()
+            barrier()
+            t0 = time.perf_counter()
+            ya = tnd.nfft_adjoint(x4, p4, b4, bandwidth=128, cutoff=4, gather=False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            sizes = [tnd.batch_range(B4, r, world)[1] - tnd.batch_range(B4, r, world)[0] for r in range(world)]
+            yfull = tnd._all_gather_rows(ya, sizes, None)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            yf = tnd.nfft_forward(yfull, p4, b4, cutoff=4, real_output=True, gather=True)
+            barrier()
+            t3 = time.perf_counter()
+            if it >= 2:
+                t_adj.append(max_over_ranks(t1 - t0)); t_gather.append(max_over_ranks(t2 - t1))
+                t_fwd.append(max_over_ranks(t3 - t2)); t_total.append(max_over_ranks(t3 - t0))
+            del ya, yfull, yf
+        med = lambda v: sorted(v)[len(v) // 2] * 1e3
+        gathered_bytes = B4 * (128 ** 3) * C4 * 8
+        legs["C4-sharded"] = {
+            "workload": "C4 sharded over %d GPUs: B=%d point sets x 100 000 points, 64 real columns, N=128, m=4; "
+                        "torch_nfft_amd.distributed adjoint (4 sets per rank) -> all_gather_into_tensor of the spectra "
+                        "(RCCL) -> forward + all-gather of the rows" % (world, B4),
+            "n_gpus": world, "ms_per_step_median": med(t_total), "ms_adjoint_local": med(t_adj),
+            "ms_all_gather_spectra": med(t_gather), "ms_forward_and_row_gather": med(t_fwd),
+            "all_gather_bytes_per_rank_out": gathered_bytes,
+            "all_gather_GBps_per_rank": gathered_bytes * (world - 1) / world / (med(t_gather) * 1e-3) / 1e9,
+            "value": B4 * n4 * C4 / (med(t_total) * 1e-3) / 1e6, "unit": "M point-columns/s"}
+        del p4, b4, x4
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = n_gpus * n / (elapsed / args.steps) / 1e6
-        # dominant kernel: the spreading kernel (stage "spread" = exactly one launch of it per step): the matrix-core
-        # kernel for 3-D grids of 64^3 and up with m <= 7 (unless NFFT_HIP_SPREAD selects another), else spread_kernel
+        # dominant kernel: the spreading kernel (stage "spread" = one launch of it per step, plus its empty overflow
+        # launch): the matrix-core kernel for 3-D grids of 64^3 and up with m <= 7, else spread_kernel
         W = 2 * m + 2
         mfma = d == 3 and M >= 64 and W <= 16 and os.environ.get("NFFT_HIP_SPREAD", "m")[:1] not in ("l", "r")
-        # (the matrix-core kernel has a second, "overflow" instantiation <W, true> that is launched right after it and
-        # is empty unless the points are clustered; the stage timer covers both launches)
         kname = "spread_mfma_kernel<%d, false>" % W if mfma else "spread_kernel<%d,%d>" % (d, W)
         # matrix flops the kernel issues per tap row: 3 MFMA terms x 2 x 32 x 64 x 16 per (plane, 16 points)
         mfma_flops = n * W * 3 * 2 * 32 * 64 if mfma else 0
@@ -178,7 +345,9 @@ def main():
         per_stage = {k: (v[0] / max(v[1], 1)) for k, v in stages.items() if v[1]}
         pipe_ms = sp_avg + per_stage.get("gather", 0.0) + per_stage.get("zero", 0.0)
         plan_ms = per_stage.get("plan", 0.0)
-        # both transforms run the point plan and an FFT: split by launch count for the report
+        workload = "C3: %d-D adjoint+forward, N=%d, m=%d, %d %s points per GPU, batch_size=1 per GPU, real fp32 x, " \
+                   "forward with real_output" % (d, N, m, n, "uniform" if args.dist == "uniform"
+                                                 else "clustered (8 Gaussian clusters)")
         out = {
             "metric": "Mpoints/s (adjoint+forward, 3-D N=256 m=4)",
             "value": value,
@@ -187,15 +356,16 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_step,
+            "ms_per_step_median": med_ms,
+            "ms_per_step_min": min_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            "arithmetic": ARITHMETIC,
             "data": "synthetic",
             "config": {
-                "workload": "C3: %d-D adjoint+forward, N=%d, m=%d, %d %s points per GPU, batch_size=1 per GPU, "
-                            "real fp32 x, forward with real_output" % (d, N, m, n, "uniform" if args.dist == "uniform"
-                                                                         else "clustered (8 Gaussian clusters)"),
+                "workload": workload,
                 "points_per_gpu": n, "bandwidth": N, "cutoff": m, "dim": d,
                 "parallelism": "batch-sharded x%d (one point set per GPU, no collective)" % n_gpus,
             },
@@ -206,7 +376,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(d, N, m, n),
+                "traffic": measured_traffic(kname, workload),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": sp_avg,
                 "launches": sp_cnt,
@@ -219,9 +389,10 @@ def main():
                 "achieved_incl_gather_zero_plan": alg_bytes / ((pipe_ms + plan_ms) * 1e-3) / 1e9 if pipe_ms > 0 else 0.0,
             },
             "stage_ms_per_launch": per_stage,
-            "value_with_plan_kept_across_steps": n_gpus * n / (elapsed_cached / args.steps) / 1e6,
+            "value_with_plan_kept_across_steps": n_gpus * n / (cached_ms * 1e-3) / 1e6,
+            "configs": legs,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not distributed:
             out["cpu_baseline"] = cpu_baseline(d, N, args.cpu_seconds)
         print(json.dumps(out))
     if distributed:

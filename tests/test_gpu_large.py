@@ -123,16 +123,22 @@ def test_clustered_points_overflow_launch(tn):
     assert abs(complex(lhs) - complex(rhs)) < 1e-4 * abs(complex(lhs)) + 1e-2
 
 
-def test_config_c4_shape_batched_columns_chunked(tn, monkeypatch):
+@pytest.mark.parametrize("complex_x,real_output,chunk_planes", [(False, True, 5), (True, False, 5), (True, True, 7),
+                                                                 (False, False, 3)])
+def test_config_c4_shape_batched_columns_chunked(tn, monkeypatch, complex_x, real_output, chunk_planes):
     """Config C4's structure (3-D N=128, m=4, several point sets x several columns) at a size that runs in seconds,
-    with a chunk budget that forces the plane loop: subset of frequencies vs the exact NDFT per (batch, column)."""
-    from torch_nfft_amd import ops
+    with an odd chunk budget that forces the plane loop of the planar-copy column passes (chunks that start in the
+    middle of a point set, (re, im) plane pairs for complex data): subset of frequencies vs the exact NDFT per
+    (batch, column), sparse-spectrum forward vs the exact sums, adjointness."""
     N, m, B, C, n_per = 128, 4, 3, 4, 20_000
     gen = torch.Generator(device="cuda").manual_seed(7)
     pos = torch.rand((B * n_per, 3), generator=gen, device="cuda") - 0.5
     batch = torch.arange(B * n_per, device="cuda") // n_per
     x = torch.randn((B * n_per, C), generator=gen, device="cuda")
-    monkeypatch.setenv("NFFT_HIP_CHUNK_BYTES", str(5 * (256 ** 3 * 4 + 256 * 256 * 129 * 8 + 300_000_000)))
+    if complex_x:
+        x = torch.complex(x, torch.randn((B * n_per, C), generator=gen, device="cuda"))
+    monkeypatch.setenv("NFFT_HIP_CHUNK_BYTES",
+                       str(chunk_planes * (256 ** 3 * 4 + 256 * 256 * 129 * 8 + 300_000_000)))
     y = tn.nfft_adjoint(x, pos, batch, bandwidth=N, cutoff=m)
     assert y.shape == (B, N, N, N, C)
     rng = np.random.default_rng(8)
@@ -142,12 +148,76 @@ def test_config_c4_shape_batched_columns_chunked(tn, monkeypatch):
         exact = ndft.ndft_adjoint_subset(x[sel].cpu().numpy(), pos[sel].cpu().numpy(), freqs)
         got = y[b].cpu().numpy()[tuple((freqs + N // 2).T)]
         assert rel_l2(got, exact) < T2_M4
-    z = tn.nfft_forward(y, pos, batch, cutoff=m, real_output=True)
-    assert z.shape == (B * n_per, C)
-    # <A x, A x> = <x, A^H A x>
+    z = tn.nfft_forward(y, pos, batch, cutoff=m, real_output=real_output)
+    assert z.shape == (B * n_per, C) and z.dtype == (torch.float32 if real_output else torch.complex64)
+    # <A x, A x> = Re <x, A^H A x>
     lhs = float((y.abs() ** 2).sum())
-    rhs = float((x * z).sum())
+    rhs = float((x.conj() * z).real.sum()) if complex_x else float((x * z.real).sum())
     assert abs(lhs - rhs) < 1e-4 * lhs
+    # sparse spectrum: a few non-zero (set, frequency, column) entries, exact result is a short sum per point
+    xh = torch.zeros((B, N, N, N, C), dtype=torch.complex64, device="cuda")
+    f = rng.integers(-N // 2, N // 2, size=(5, 3))
+    vals = (rng.standard_normal((B, 5, C)) + 1j * rng.standard_normal((B, 5, C))).astype(np.complex64)
+    for b in range(B):
+        for k in range(5):
+            xh[(b,) + tuple(f[k] + N // 2)] += torch.from_numpy(vals[b, k]).cuda()
+    zf = tn.nfft_forward(xh, pos, batch, cutoff=m, real_output=real_output)
+    idx = rng.integers(0, B * n_per, size=2048)
+    ph = np.exp(-2j * np.pi * (pos[idx].cpu().numpy().astype(np.float64) @ f.T.astype(np.float64)))  # [pts, 5]
+    exact = np.einsum("pk,pkc->pc", ph, vals[batch[idx].cpu().numpy()].astype(np.complex128))
+    got = zf[idx].cpu().numpy()
+    assert rel_l2(got, exact.real if real_output else exact) < T2_M4
+
+
+@pytest.mark.parametrize("chunk_gib", [None, 3])
+def test_config_c4_stated_shape_one_gpu_share(tn, monkeypatch, chunk_gib):
+    """Config C4 at its stated shape, one GPU's share of the 8-way sharded batch: 3-D N=128, m=4, C=64 real columns,
+    B=4 point sets of 10^5 points (n per set assumed, BASELINE.json gives none).  Reference
+    layout [B, N, N, N, C] (docs/source/theory/dataformat.rst:43-63; column loop of the reference:
+    csrc/cuda/spatial_window_operations.cu:103-171).  With the default chunk budget and with a small one (3 GiB:
+    the plane loop runs ~10 times and chunks start in the middle of a point set's columns).
+      * adjoint: EVERY (set, column) pair on a frequency subset vs the exact NDFT (oracle.ndft.ndft_adjoint_subset);
+      * forward: sparse spectrum vs the exact sums on a sample of points, all 64 columns;
+      * adjointness <A x, xh> = <x, A^H xh> at full size."""
+    N, m, B, C, n_per = 128, 4, 4, 64, 100_000
+    if chunk_gib is not None:
+        monkeypatch.setenv("NFFT_HIP_CHUNK_BYTES", str(chunk_gib << 30))
+    gen = torch.Generator(device="cuda").manual_seed(64)
+    n = B * n_per
+    pos = torch.rand((n, 3), generator=gen, device="cuda") - 0.5
+    batch = torch.arange(n, device="cuda") // n_per
+    x = torch.randn((n, C), generator=gen, device="cuda")
+    y = tn.nfft_adjoint(x, pos, batch, bandwidth=N, cutoff=m)
+    assert y.shape == (B, N, N, N, C) and y.dtype == torch.complex64
+    rng = np.random.default_rng(65)
+    freqs = rng.integers(-N // 2, N // 2, size=(24, 3))
+    worst = 0.0
+    for b in range(B):
+        sel = slice(b * n_per, (b + 1) * n_per)
+        exact = ndft.ndft_adjoint_subset(x[sel].cpu().numpy(), pos[sel].cpu().numpy(), freqs)  # [24, 64]
+        got = y[b].cpu().numpy()[tuple((freqs + N // 2).T)]
+        assert got.shape == exact.shape == (24, C)
+        for c in range(C):
+            worst = max(worst, rel_l2(got[:, c], exact[:, c]))
+    assert worst < T2_M4
+    # forward of a sparse spectrum
+    xh = torch.zeros((B, N, N, N, C), dtype=torch.complex64, device="cuda")
+    f = rng.integers(-N // 2, N // 2, size=(4, 3))
+    vals = (rng.standard_normal((B, 4, C)) + 1j * rng.standard_normal((B, 4, C))).astype(np.complex64)
+    for b in range(B):
+        for k in range(4):
+            xh[(b,) + tuple(f[k] + N // 2)] += torch.from_numpy(vals[b, k]).cuda()
+    z = tn.nfft_forward(xh, pos, batch, cutoff=m, real_output=True)
+    assert z.shape == (n, C) and z.dtype == torch.float32
+    idx = rng.integers(0, n, size=1024)
+    ph = np.exp(-2j * np.pi * (pos[idx].cpu().numpy().astype(np.float64) @ f.T.astype(np.float64)))
+    exact = np.einsum("pk,pkc->pc", ph, vals[batch[idx].cpu().numpy()].astype(np.complex128)).real
+    got = z[idx].cpu().numpy()
+    assert max(rel_l2(got[:, c], exact[:, c]) for c in range(C)) < T2_M4
+    # adjointness: <A x, xh> = <x, A^H xh>; with a real x only Re(A^H xh) enters
+    lhs = complex(torch.sum(y * xh.conj()))
+    rhs = float(torch.sum(x * z))
+    assert abs(lhs.real - rhs) < 1e-4 * abs(lhs.real) + 1e-2
 
 
 def test_config_c5_fastsum_1m_x_1m(tn):

@@ -544,3 +544,29 @@ def test_clustered_points_many_per_tile(tn):
     ex = ndft.ndft_adjoint_subset(x, pos, sub)[:, 0]
     got = host(ya)[0][tuple((sub + 16).T)]
     assert rel_l2(got, ex) < T2[4]
+
+
+def test_columns_of_very_different_magnitude(tn):
+    """Columns (and point sets) whose magnitudes differ by many orders: the matrix-core spreading kernel scales its f16
+    operands per work item and column, so every column keeps fp32-grade accuracy RELATIVE TO ITSELF (a single global
+    scale would leave ~12 bits at 1e-6 and flush 1e-12 to zero; the reference spreads each column independently in
+    fp32, csrc/cuda/spatial_window_operations.cu:103-171)."""
+    rng = np.random.default_rng(4321)
+    n, N, m = 30000, 64, 4
+    pos = (rng.random((n, 3)) - 0.5).astype(np.float32)
+    batch = (np.arange(n) >= n // 2).astype(np.int64)
+    scales = np.array([1.0, 1e-6, 1e-12, 1e9], np.float32)
+    x = (rng.standard_normal((n, 4)) * scales[None, :]).astype(np.float32)
+    x[n // 2:] *= np.float32(1e-5)  # the second point set is another 1e-5 smaller
+    y = host(tn.nfft_adjoint(dev(x), dev(pos), dev(batch), bandwidth=N, cutoff=m))
+    ref = nfft_ref.nfft_adjoint(x.astype(np.float64), pos, batch, N=N, m=m)
+    for b in range(2):
+        for c in range(4):
+            assert rel_l2(y[b, ..., c], ref[b, ..., c]) < 2e-6, (b, c)
+    # complex coefficients: real and imaginary planes of different magnitude
+    xc = (x[:, 0] + 1j * x[:, 2]).astype(np.complex64)
+    yc = host(tn.nfft_adjoint(dev(xc), dev(pos), None, bandwidth=N, cutoff=m))
+    ri = nfft_ref.nfft_adjoint(1j * x[:, 2].astype(np.float64), pos, None, N=N, m=m)
+    yi = host(tn.nfft_adjoint(dev((1j * x[:, 2]).astype(np.complex64)), dev(pos), None, bandwidth=N, cutoff=m))
+    assert rel_l2(yi, ri) < 2e-6
+    assert rel_l2(yc, nfft_ref.nfft_adjoint(xc.astype(np.complex128), pos, None, N=N, m=m)) < 2e-6

@@ -134,3 +134,32 @@ def test_drop_in_package_name_and_exact_transforms():
     batch = torch.tensor([0, 0, 0, 1, 1, 2, 2])
     A = tn.exact_gaussian_matrix(0.3, pos, batch=batch)
     assert A.shape == (7, 7) and float(A[0, 3]) == 0.0 and float(A[5, 6]) > 0.0
+
+
+def test_bench_self_launches_ranks_before_touching_the_gpu(monkeypatch):
+    """`bench.py --gpus N` outside a launcher becomes the parent of a torch.distributed.run job with N ranks on
+    127.0.0.1 (and exits with the job's code); under a launcher (WORLD_SIZE set) it does not spawn."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("_bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"] = cmd
+        seen["env"] = env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7  # a failed worker fails the bench
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

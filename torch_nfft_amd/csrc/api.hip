@@ -160,16 +160,13 @@ struct Carve {
 
 bool spread_reg_enabled() { return subblock_plan_enabled(); }
 
-// xs holds Cr * n gathered coefficients followed (64-float aligned) by max |x|
-inline const float *maxabs_of(const float *xs, int64_t n, int64_t Cr) { return xs + align_up(n * Cr, 64); }
-
 int spread_any(const Geom &g, const PlanLayout &L, const void *plan, const float *xs, int64_t n, int64_t Cr,
                int64_t p0, int64_t np, float *grid, hipStream_t s)
 {
     if (spread_mfma_supported(g)) {
         { StageTimer t(kStageZero, s); NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(np * g.cells * 4), s)); }
         StageTimer t(kStageSpread, s);
-        return launch_spread_mfma(g, L, plan, xs, maxabs_of(xs, n, Cr), n, Cr, p0, np, grid, s);
+        return launch_spread_mfma(g, L, plan, xs, n, Cr, p0, np, grid, s);
     }
     if (spread_reg_supported(g) && spread_reg_enabled()) {
         StageTimer t(kStageSpread, s);
@@ -318,7 +315,7 @@ int nfft_hip_spread(const nfft_hip_problem *p, const void *plan, const float *xr
     hipStream_t s = (hipStream_t)stream;
     const int64_t planes = p->batch_size * real_columns;
     if (planes > 32768) { set_error("Input mismatch: too many planes for one spread call"); return NFFT_HIP_EINVAL; }
-    if (int rc = launch_gather_rows(g, L, plan, p->num_points, xr, real_columns, scratch, g.wide ? scratch + align_up(p->num_points * real_columns, 64) : nullptr, s)) return rc;
+    if (int rc = launch_gather_rows(g, L, plan, p->num_points, xr, real_columns, scratch, s)) return rc;
     return spread_any(g, L, plan, scratch, p->num_points, real_columns, 0, planes, grid, s);
 }
 
@@ -358,7 +355,7 @@ static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64
         if (int rc = launch_plan_points(c.g, c.L, pos, batch, c.n, c.B, ws + c.off_plan, s)) return rc;
         plan = ws + c.off_plan;
     }
-    { StageTimer t(kStageGather, s); if (int rc = launch_gather_rows(c.g, c.L, plan, c.n, (const float *)x, c.Cr, xs, c.g.wide ? xs + align_up(c.n * c.Cr, 64) : nullptr, s)) return rc; }
+    { StageTimer t(kStageGather, s); if (int rc = launch_gather_rows(c.g, c.L, plan, c.n, (const float *)x, c.Cr, xs, s)) return rc; }
     for (int64_t p0 = 0; p0 < c.total_planes; p0 += c.chunk_planes) {
         const int64_t np = std::min(c.chunk_planes, c.total_planes - p0);
         if (int rc = spread_any(c.g, c.L, plan, xs, c.n, c.Cr, p0, np, grid, s)) return rc;

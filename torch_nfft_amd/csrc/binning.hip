@@ -301,11 +301,9 @@ segment_split_kernel(Geom g, int npl /* point sets x pencils */, int runs, int t
 
 // xs[c, slot] = xr[perm[slot], c]  (tile-ordered, column-major copy of the real coefficient columns)
 __global__ void __launch_bounds__(256) gather_rows_kernel(const int *__restrict__ perm, const float *__restrict__ xr,
-                                                         float *__restrict__ xs, int64_t n, int64_t cols,
-                                                         unsigned *__restrict__ maxabs_bits)
+                                                         float *__restrict__ xs, int64_t n, int64_t cols)
 {
     const int64_t total = n * cols;
-    float mx = 0.0f;
     // eight elements per thread and step: first the eight permutation entries, then the eight (random) coefficient
     // reads, so that a wave has 8 x 64 independent loads in flight
     constexpr int UN = 8;
@@ -331,20 +329,7 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const int *__restrict_
             if (e < total) {
                 const int64_t slot = e / cols, c = e - slot * cols;
                 xs[c * n + slot] = v[q];
-                mx = fmaxf(mx, fabsf(v[q]));
             }
-        }
-    }
-    if (maxabs_bits) {
-        // one atomic per workgroup; non-negative floats order like their bit patterns (NaN / inf inputs saturate the
-        // scale, which the consumer clamps)
-        __shared__ float wmax[4];
-        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-            if (mx > 0.0f) atomicMax(maxabs_bits, __float_as_uint(mx));
         }
     }
 }
@@ -424,13 +409,11 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
 }
 
 int launch_gather_rows(const Geom &g, const PlanLayout &L, const void *plan, int64_t n, const float *xr, int64_t cols,
-                       float *xs, float *maxabs, hipStream_t stream)
+                       float *xs, hipStream_t stream)
 {
     const int *perm = (const int *)((const char *)plan + L.off_perm);
-    if (maxabs) NFFT_HIP_CHECK(hipMemsetAsync(maxabs, 0, 4, stream));
     if (n * cols > 0)
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n * cols, 256)), dim3(256), 0, stream, perm, xr, xs, n, cols,
-                           (unsigned *)maxabs);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n * cols, 256)), dim3(256), 0, stream, perm, xr, xs, n, cols);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -8,9 +8,8 @@ namespace nfft {
 int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, const int64_t *batch, int64_t n, int64_t B,
                        void *plan, hipStream_t stream);
 // xs[c * n + slot] = xr[perm[slot] * cols + c]
-// also writes max |xr| to *maxabs (device, may be null)
 int launch_gather_rows(const Geom &g, const PlanLayout &L, const void *plan, int64_t n, const float *xr, int64_t cols,
-                       float *xs, float *maxabs, hipStream_t stream);
+                       float *xs, hipStream_t stream);
 
 // spread.hip: grid[p, :] += ... for local planes p in [0, nplanes); global plane plane0 + p = b * Cr + cr
 int launch_spread(const Geom &g, const PlanLayout &L, const void *plan, const float *xs, int64_t n, int64_t Cr,
@@ -22,9 +21,9 @@ bool spread_reg_supported(const Geom &g);
 int launch_spread_reg(const Geom &g, const PlanLayout &L, const void *plan, const float *xs, int64_t n, int64_t Cr,
                       int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream);
 
-// spread_mfma.hip: matrix-core spreading for the wide 3-D tiling (g.wide); needs max |x| for its f16 operand scaling
+// spread_mfma.hip: matrix-core spreading for the wide 3-D tiling (g.wide)
 bool spread_mfma_supported(const Geom &g);
-int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, const float *xs, const float *maxabs,
+int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, const float *xs,
                        int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream);
 
 // interp.hip: yr[perm[slot] * Cr + cr] = sum over taps of grid[p, ...]

@@ -83,13 +83,14 @@ struct __align__(16) MfmaLds {
     int raw_have[2][kSlots];
     int raw_slab[2][kNKB];
     int task_counter[2];
+    unsigned xmax_bits;                   // max |x| over the work item's points (bit pattern; staging of the f16 scale)
     int2 sched[kMaxSegSlabs + 8];         // per slab: {K-blocks before it, point offset}; padded with the totals
 };
 
 template <int W, bool OVERFLOW>
 __global__ void __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *__restrict__ spos,
-                   const float *__restrict__ xs, const float *__restrict__ maxabs, const int64_t n, const int Cr,
+                   const float *__restrict__ xs, const int64_t n, const int Cr,
                    const int plane0, float *__restrict__ grid, const int seg_slabs, const int nsegm,
                    const int *__restrict__ first_end, const int4 *__restrict__ overflow)
 {
@@ -138,10 +139,25 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     const float sc = win_exp_scale(m);
     float norm = win_norm(m);
     norm = norm * norm * norm;
-    // x is scaled into [-1, 1] by a power of two so that every operand fits f16; undone at the flush
+    const float *const xcol = xs + (int64_t)cr * n;
+    // x is scaled into [-1, 1] by a power of two so that every operand fits f16; undone at the flush.  The scale is
+    // this work item's own: the largest |x| among the points of its slab range in its column -- columns, point sets or
+    // regions of very different magnitude each keep their full ~22 bits (a single global scale would flush a column
+    // 1e-10 below the largest one to zero; the reference spreads every column independently in fp32).
+    if (tid == 0) L.xmax_bits = 0u;
+    __syncthreads();
+    {
+        float mx = 0.0f;
+        const int p_end = tile_offsets[bin0 + se];
+        for (int j = tile_offsets[bin0 + sb] + tid; j < p_end; j += kMfmaThreads) mx = fmaxf(mx, fabsf(xcol[j]));
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        // non-negative floats order like their bit patterns (inf saturates the scale, which is clamped below)
+        if (lane == 0 && mx > 0.0f) atomicMax(&L.xmax_bits, __float_as_uint(mx));
+    }
+    __syncthreads();
     float xscale = 1.0f;
     {
-        const float mx = *maxabs;
+        const float mx = __uint_as_float(L.xmax_bits);
         if (mx > 1.0e-30f && mx < 3.0e38f) {  // (tinier inputs: 1 / scale would overflow; their taps flush to zero anyway)
             int e;
             frexpf(mx, &e);
@@ -150,7 +166,6 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     }
     const float inv_xscale = 1.0f / xscale;
     const float unscale = xscale * norm * (1.0f / (kOpScale * kOpScale));
-    const float *const xcol = xs + (int64_t)cr * n;
     float *const gplane = grid + (int64_t)plane_local * g.cells;
 
     f32x16 acc0 = 0.0f, acc1 = 0.0f;
@@ -403,7 +418,7 @@ bool spread_mfma_supported(const Geom &g) { return g.dim == 3 && g.wide; }
 
 template <int W>
 static int launch_mfma_t(const Geom &g, const PlanLayout &L, const void *plan, const int *to, const float *spos,
-                         const float *xs, const float *maxabs, int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes,
+                         const float *xs, int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes,
                          float *grid, hipStream_t stream)
 {
     // Ranges per pencil: about 5-6 workgroups per CU balance the tail of the launch against the 2m+1 halo planes
@@ -426,19 +441,19 @@ static int launch_mfma_t(const Geom &g, const PlanLayout &L, const void *plan, c
     const char *base = (const char *)plan;
     const int *first_end = (const int *)(base + L.off_cursor);
     hipLaunchKernelGGL((spread_mfma_kernel<W, false>), blocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to, spos,
-                       xs, maxabs, n, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, (const int4 *)nullptr);
+                       xs, n, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, (const int4 *)nullptr);
     if (L.two_level) {
         // the pieces the plan cut off dense ranges (none for uniform inputs: the workgroups then leave at once)
         const int4 *overflow = (const int4 *)(base + L.off_tmp);
         const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
         hipLaunchKernelGGL((spread_mfma_kernel<W, true>), oblocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to, spos,
-                           xs, maxabs, n, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, overflow);
+                           xs, n, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, overflow);
     }
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, const float *xs, const float *maxabs,
+int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, const float *xs,
                        int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream)
 {
     const char *base = (const char *)plan;
@@ -446,14 +461,14 @@ int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, con
     const float *spos = (const float *)(base + L.off_spos);
     if (nplanes <= 0 || n <= 0) return 0;
     switch (g.m) {
-    case 1: return launch_mfma_t<4>(g, L, plan, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
-    case 2: return launch_mfma_t<6>(g, L, plan, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
-    case 3: return launch_mfma_t<8>(g, L, plan, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
-    case 4: return launch_mfma_t<10>(g, L, plan, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
-    case 5: return launch_mfma_t<12>(g, L, plan, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
-    case 6: return launch_mfma_t<14>(g, L, plan, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
-    case 7: return launch_mfma_t<16>(g, L, plan, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
-    case 8: return launch_mfma_t<18>(g, L, plan, to, spos, xs, maxabs, n, Cr, plane0, nplanes, grid, stream);
+    case 1: return launch_mfma_t<4>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 2: return launch_mfma_t<6>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 3: return launch_mfma_t<8>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 4: return launch_mfma_t<10>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 5: return launch_mfma_t<12>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 6: return launch_mfma_t<14>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 7: return launch_mfma_t<16>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 8: return launch_mfma_t<18>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
     }
     set_error("cutoff m must be in 1..8");
     return 1;
