@@ -150,8 +150,13 @@ def test_config_c4_shape_batched_columns_chunked(tn, monkeypatch, complex_x, rea
         assert rel_l2(got, exact) < T2_M4
     z = tn.nfft_forward(y, pos, batch, cutoff=m, real_output=real_output)
     assert z.shape == (B * n_per, C) and z.dtype == (torch.float32 if real_output else torch.complex64)
-    # <A x, A x> = Re <x, A^H A x>
+    # <A x, A x> = Re <x, A^H A x>  (a complex x needs the complex result of A^H: with real_output only its real part
+    # exists, which is then compared with the real part of the complex call instead)
     lhs = float((y.abs() ** 2).sum())
+    if complex_x and real_output:
+        zc = tn.nfft_forward(y, pos, batch, cutoff=m, real_output=False)
+        assert rel_l2(z.cpu().numpy(), zc.real.cpu().numpy()) < 2e-6
+        z = zc
     rhs = float((x.conj() * z).real.sum()) if complex_x else float((x * z.real).sum())
     assert abs(lhs - rhs) < 1e-4 * lhs
     # sparse spectrum: a few non-zero (set, frequency, column) entries, exact result is a short sum per point
