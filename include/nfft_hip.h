@@ -105,8 +105,11 @@ int nfft_hip_plan_points(const nfft_hip_problem *p, const float *pos, const int6
 /* Spreading (adjoint gridding):  grid[(b*Cr + cr), u] += xr[i, cr] * prod_k psi_k(i, u_k)
  * over real columns cr (a complex x is viewed as 2C real columns).  Replaces
  * real_/complex_adjoint_window_convolution_kernel (spatial_window_operations.cu:103-211).
- *   grid  float32 [B*Cr, (2N)^dim] real planes; zero-filled by this call.
- *   scratch  float32 [roundup(n * Cr, 64) + 64]: the tile-ordered copy of xr and its maximum magnitude. */
+ *   grid  float32 [B*Cr, (2N)^dim] real planes; every cell is written by this call.
+ *   scratch  nfft_hip_spread_scratch_bytes(p, Cr) bytes: the tile-ordered copy of xr (n * Cr floats, or one per plan
+ *            entry when the problem is sparse enough for the owner-computes kernel, whose plan enters a point into
+ *            every tile its window touches). */
+int64_t nfft_hip_spread_scratch_bytes(const nfft_hip_problem *p, int64_t real_columns);
 int nfft_hip_spread(const nfft_hip_problem *p, const void *plan, const float *xr, int64_t real_columns,
                     float *grid, float *scratch, void *stream);
 

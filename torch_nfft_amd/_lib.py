@@ -26,6 +26,7 @@ SYMBOLS = (
     "nfft_hip_forward_planned",
     "nfft_hip_plan_bytes",
     "nfft_hip_plan_points",
+    "nfft_hip_spread_scratch_bytes",
     "nfft_hip_spread",
     "nfft_hip_interpolate",
     "nfft_hip_spectral_multiply",
@@ -93,6 +94,8 @@ def load():
     lib.nfft_hip_plan_bytes.restype = i64
     lib.nfft_hip_plan_points.argtypes = [P, vp, vp, vp, i64, vp]
     lib.nfft_hip_plan_points.restype = ci
+    lib.nfft_hip_spread_scratch_bytes.argtypes = [P, i64]
+    lib.nfft_hip_spread_scratch_bytes.restype = i64
     lib.nfft_hip_spread.argtypes = [P, vp, vp, i64, vp, vp, vp]
     lib.nfft_hip_spread.restype = ci
     lib.nfft_hip_interpolate.argtypes = [P, vp, vp, i64, vp, vp]

@@ -99,7 +99,57 @@ SpreadMode spread_mode()
     return mode;
 }
 
+int owned_override()
+{
+    static const int v = [] {
+        const char *env = std::getenv("NFFT_HIP_OWNED");
+        if (env && env[0] == '0') return 0;
+        if (env && env[0] == '1') return 1;
+        return -1;
+    }();
+    return v;
+}
+
 namespace {
+
+// The point plan of a problem: the tile-sorted points (pencils with halo: what the interpolation kernels and the
+// scatter spreading kernels walk) and, for sparse 3-D problems, a second sort by owned 32 x 64 tiles with an entry
+// per touched tile for the owner-computes spreading kernel (common.h choose_owned), stored behind the first.
+struct PlanSet {
+    Geom g;
+    PlanLayout L;
+    bool owned;
+    Geom go;
+    PlanLayout Lo;
+    int64_t off_own, total;
+    const Geom &spread_geom() const { return owned ? go : g; }
+    const PlanLayout &spread_layout() const { return owned ? Lo : L; }
+    const void *spread_plan(const void *plan) const { return owned ? (const char *)plan + off_own : (const char *)plan; }
+};
+PlanSet plan_set(const nfft_hip_problem *p)
+{
+    PlanSet ps;
+    ps.g = make_geom(p->dim, p->N, p->m);
+    ps.L = plan_layout(ps.g, p->num_points, p->batch_size);
+    ps.owned = choose_owned(p->dim, p->N, p->m, p->num_points, p->batch_size);
+    ps.go = ps.g;
+    ps.Lo = ps.L;
+    ps.off_own = 0;
+    ps.total = ps.L.total;
+    if (ps.owned) {
+        ps.go = make_geom(p->dim, p->N, p->m, true);
+        ps.Lo = plan_layout(ps.go, p->num_points, p->batch_size);
+        ps.off_own = align_up(ps.L.total, 256);
+        ps.total = ps.off_own + ps.Lo.total;
+    }
+    return ps;
+}
+int build_plans(const PlanSet &ps, const float *pos, const int64_t *batch, int64_t n, int64_t B, void *plan, hipStream_t s)
+{
+    if (int rc = launch_plan_points(ps.g, ps.L, pos, batch, n, B, plan, s)) return rc;
+    if (ps.owned) return launch_plan_points(ps.go, ps.Lo, pos, batch, n, B, (char *)plan + ps.off_own, s);
+    return 0;
+}
 
 // interpolation: matrix-core kernel for the wide 3-D tiling unless NFFT_HIP_GATHER=lds
 int gather_any(const Geom &g, const PlanLayout &L, const void *plan, const float *grid, int64_t n, int64_t Cr,
@@ -150,8 +200,9 @@ int64_t grid_budget_bytes()
 }
 
 struct Carve {
-    Geom g;
-    PlanLayout L;
+    PlanSet ps;
+    Geom g;        // = ps.g
+    PlanLayout L;  // = ps.L
     int64_t n, B, C, Cr, total_planes, chunk_planes;
     int64_t half_cells;
     bool colfft;  // pruned column passes (colfft.hip) instead of the full dim-dimensional rocFFT transform
@@ -164,7 +215,8 @@ int spread_any(const Geom &g, const PlanLayout &L, const void *plan, const float
                int64_t p0, int64_t np, float *grid, hipStream_t s)
 {
     if (spread_mfma_supported(g)) {
-        { StageTimer t(kStageZero, s); NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(np * g.cells * 4), s)); }
+        // (the owner-computes variant writes every cell itself)
+        if (!g.owned) { StageTimer t(kStageZero, s); NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(np * g.cells * 4), s)); }
         StageTimer t(kStageSpread, s);
         return launch_spread_mfma(g, L, plan, xs, n, Cr, p0, np, grid, s);
     }
@@ -196,13 +248,14 @@ bool colfft_enabled()
 // planes_per_col: 2 when a column owns a (re, im) pair of real planes, else 1
 int make_carve(const nfft_hip_problem *p, int planes_per_col, bool need_xs, FftKind kind, Carve &c)
 {
-    c.g = make_geom(p->dim, p->N, p->m);
+    c.ps = plan_set(p);
+    c.g = c.ps.g;
+    c.L = c.ps.L;
     c.n = p->num_points;
     c.B = p->batch_size;
     c.C = p->num_columns;
     c.Cr = c.C * planes_per_col;
     c.total_planes = c.B * c.Cr;
-    c.L = plan_layout(c.g, c.n, c.B);
     c.half_cells = (int64_t)(c.g.M / 2 + 1);
     for (int a = 0; a < 2; ++a) c.half_cells *= c.g.Ma[a];
     c.colfft = colfft_supported(c.g) && colfft_enabled();
@@ -228,8 +281,8 @@ int make_carve(const nfft_hip_problem *p, int planes_per_col, bool need_xs, FftK
         }
     }
     int64_t o = 0;
-    c.off_plan = o; o = align_up(o + c.L.total, 256);
-    c.off_xs = o;   o = align_up(o + (need_xs ? (align_up(c.n * c.Cr, 64) + 64) * 4 : 0), 256);
+    c.off_plan = o; o = align_up(o + c.ps.total, 256);
+    c.off_xs = o;   o = align_up(o + (need_xs ? (align_up(c.ps.spread_layout().cap * c.Cr, 64) + 64) * 4 : 0), 256);
     c.off_grid = o; o = align_up(o + chunk * c.g.cells * 4, 256);
     c.off_spec = o; o = align_up(o + chunk * c.half_cells * 8, 256);
     c.off_col = o;  o = align_up(o + (c.colfft ? colfft_scratch_bytes(c.g, chunk) : 0), 256);
@@ -290,28 +343,34 @@ int64_t nfft_hip_forward_workspace_bytes(const nfft_hip_problem *p, int x_is_com
 int64_t nfft_hip_plan_bytes(const nfft_hip_problem *p)
 {
     if (validate(p)) return -1;
-    const Geom g = make_geom(p->dim, p->N, p->m);
-    return plan_layout(g, p->num_points, p->batch_size).total;
+    return plan_set(p).total;
 }
 
 int nfft_hip_plan_points(const nfft_hip_problem *p, const float *pos, const int64_t *batch, void *plan,
                          int64_t plan_bytes, void *stream)
 {
     if (int rc = validate(p)) return rc;
-    const Geom g = make_geom(p->dim, p->N, p->m);
-    const PlanLayout L = plan_layout(g, p->num_points, p->batch_size);
-    if (!plan || plan_bytes < L.total) { set_error("plan buffer too small"); return NFFT_HIP_EWORKSPACE; }
+    const PlanSet ps = plan_set(p);
+    if (!plan || plan_bytes < ps.total) { set_error("plan buffer too small"); return NFFT_HIP_EWORKSPACE; }
     if (p->num_points > 0 && !pos) { set_error("Input mismatch: pos is null"); return NFFT_HIP_EINVAL; }
     StageTimer t(kStagePlan, (hipStream_t)stream);
-    return launch_plan_points(g, L, pos, batch, p->num_points, p->batch_size, plan, (hipStream_t)stream);
+    return build_plans(ps, pos, batch, p->num_points, p->batch_size, plan, (hipStream_t)stream);
+}
+
+int64_t nfft_hip_spread_scratch_bytes(const nfft_hip_problem *p, int64_t real_columns)
+{
+    if (validate(p) || real_columns < 0) return -1;
+    return (align_up(plan_set(p).spread_layout().cap * real_columns, 64) + 64) * 4;
 }
 
 int nfft_hip_spread(const nfft_hip_problem *p, const void *plan, const float *xr, int64_t real_columns, float *grid,
                     float *scratch, void *stream)
 {
     if (int rc = validate(p)) return rc;
-    const Geom g = make_geom(p->dim, p->N, p->m);
-    const PlanLayout L = plan_layout(g, p->num_points, p->batch_size);
+    const PlanSet ps = plan_set(p);
+    const Geom &g = ps.spread_geom();
+    const PlanLayout &L = ps.spread_layout();
+    plan = ps.spread_plan(plan);
     hipStream_t s = (hipStream_t)stream;
     const int64_t planes = p->batch_size * real_columns;
     if (planes > 32768) { set_error("Input mismatch: too many planes for one spread call"); return NFFT_HIP_EINVAL; }
@@ -352,13 +411,16 @@ static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64
 
     if (!ext_plan) {
         StageTimer t(kStagePlan, s);
-        if (int rc = launch_plan_points(c.g, c.L, pos, batch, c.n, c.B, ws + c.off_plan, s)) return rc;
+        if (int rc = build_plans(c.ps, pos, batch, c.n, c.B, ws + c.off_plan, s)) return rc;
         plan = ws + c.off_plan;
     }
-    { StageTimer t(kStageGather, s); if (int rc = launch_gather_rows(c.g, c.L, plan, c.n, (const float *)x, c.Cr, xs, s)) return rc; }
+    const Geom &gs = c.ps.spread_geom();
+    const PlanLayout &Ls = c.ps.spread_layout();
+    const void *plan_s = c.ps.spread_plan(plan);
+    { StageTimer t(kStageGather, s); if (int rc = launch_gather_rows(gs, Ls, plan_s, c.n, (const float *)x, c.Cr, xs, s)) return rc; }
     for (int64_t p0 = 0; p0 < c.total_planes; p0 += c.chunk_planes) {
         const int64_t np = std::min(c.chunk_planes, c.total_planes - p0);
-        if (int rc = spread_any(c.g, c.L, plan, xs, c.n, c.Cr, p0, np, grid, s)) return rc;
+        if (int rc = spread_any(gs, Ls, plan_s, xs, c.n, c.Cr, p0, np, grid, s)) return rc;
         if (c.colfft) {
             const bool own_rows = own_row_passes(c.g);
             if (own_rows) { StageTimer t(kStageFft, s); if (int rc = launch_row_r2c(c.g, grid, ws + c.off_col, c.chunk_planes, np, spec, s)) return rc; }
@@ -402,6 +464,7 @@ static int forward_impl(const nfft_hip_problem *p, const float *pos, const int64
     void *work = ws + c.off_work;
 
     if (!ext_plan) {
+        // (only the first sort: the forward transform never spreads)
         StageTimer t(kStagePlan, s);
         if (int rc = launch_plan_points(c.g, c.L, pos, batch, c.n, c.B, ws + c.off_plan, s)) return rc;
         plan = ws + c.off_plan;
@@ -484,8 +547,8 @@ int fastsum_carve(const nfft_hip_problem *src, const nfft_hip_problem *tgt, int 
     int64_t band = src->batch_size * src->num_columns * 8;
     for (int d = 0; d < src->dim; ++d) band *= src->N;
     f.band_bytes = align_up(band, 256);
-    f.plan_s = own_plans ? align_up(a.L.total, 256) : 0;
-    f.plan_t = own_plans && !shared_points ? align_up(b.L.total, 256) : 0;
+    f.plan_s = own_plans ? align_up(a.ps.total, 256) : 0;
+    f.plan_t = own_plans && !shared_points ? align_up(b.ps.total, 256) : 0;
     f.inner = std::max(a.total, b.total);
     int64_t o = 0;
     f.off_band = o;   o += f.band_bytes;
@@ -516,17 +579,15 @@ int fastsum_impl(const nfft_hip_problem *src, const float *sources, const int64_
         if (!targets) { set_error("Input mismatch: targets is null"); return NFFT_HIP_EINVAL; }
         {
             StageTimer t(kStagePlan, s);
-            const Geom g = make_geom(src->dim, src->N, src->m);
-            if (int rc = launch_plan_points(g, plan_layout(g, src->num_points, src->batch_size), sources, source_batch,
-                                            src->num_points, src->batch_size, ws + f.off_plan_s, s)) return rc;
+            if (int rc = build_plans(plan_set(src), sources, source_batch, src->num_points, src->batch_size,
+                                     ws + f.off_plan_s, s)) return rc;
         }
         source_plan = ws + f.off_plan_s;
         target_plan = source_plan;
         if (!shared) {
             StageTimer t(kStagePlan, s);
-            const Geom g = make_geom(tgt->dim, tgt->N, tgt->m);
-            if (int rc = launch_plan_points(g, plan_layout(g, tgt->num_points, tgt->batch_size), targets, target_batch,
-                                            tgt->num_points, tgt->batch_size, ws + f.off_plan_t, s)) return rc;
+            if (int rc = build_plans(plan_set(tgt), targets, target_batch, tgt->num_points, tgt->batch_size,
+                                     ws + f.off_plan_t, s)) return rc;
             target_plan = ws + f.off_plan_t;
         }
     }

@@ -21,6 +21,7 @@ constexpr int kMaxPencilsLds = 8192;    // first-level bins that fit an LDS hist
 PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)
 {
     PlanLayout L;
+    L.cap = g.owned ? 4 * n : n;
     L.ntiles = (int64_t)g.tiles_per_batch * B * g.SB;  // (tile, sub-block) bins
     L.npencils = (int64_t)g.nta[1] * g.nta[2] * B * g.l1seg;  // first-level bins: (batch, pencil, segment)
     L.nblocks = (n + kSortBlockPoints - 1) / kSortBlockPoints;
@@ -31,19 +32,20 @@ PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)
     int64_t o = 0;
     L.off_offsets = o; o = align_up(o + (L.ntiles + 1) * 4, 256);
     L.off_cursor = o;  o = align_up(o + (L.ntiles + 1) * 4, 256);
-    L.off_perm = o;    o = align_up(o + n * 4, 256);
-    L.off_spos = o;    o = align_up(o + n * g.dim * 4, 256);
+    L.off_perm = o;    o = align_up(o + L.cap * 4, 256);
+    L.off_spos = o;    o = align_up(o + L.cap * g.dim * 4, 256);
     L.off_scan = o;    o = align_up(o + L.scan_bytes, 256);
     // scratch of the two-level sort: per-(pencil, block) counts + their scan, and the pencil-ordered records
     L.off_hist = o;    o = align_up(o + (L.two_level ? scan_items * 4 : 0), 256);
     L.off_hscan = o;   o = align_up(o + (L.two_level ? scan_items * 4 : 0), 256);
-    L.off_tmp = o;     o = align_up(o + (L.two_level ? n * 16 : 0), 256);
+    L.off_tmp = o;     o = align_up(o + (L.two_level ? L.cap * 16 : 0), 256);
     L.total = o;
     return L;
 }
 
-__device__ __forceinline__ int point_tile(const Geom &g, const float *__restrict__ pos, const int64_t *__restrict__ batch,
-                                          int64_t i, int64_t B)
+// Plan bins of point i: one, or up to four for the owned tiling (one per tile its window touches).
+__device__ __forceinline__ int point_tiles(const Geom &g, const float *__restrict__ pos, const int64_t *__restrict__ batch,
+                                           int64_t i, int64_t B, int tiles[4])
 {
     int cell[3] = {0, 0, 0};
     for (int u = 0; u < g.dim; ++u) {
@@ -51,16 +53,26 @@ __device__ __forceinline__ int point_tile(const Geom &g, const float *__restrict
         split_cell(pos[i * g.dim + u], g.M, cell[u + 3 - g.dim], fr);
     }
     int64_t b = batch ? batch[i] : 0;
-    b = b < 0 ? 0 : (b >= B ? B - 1 : b);
-    return ((int)b * g.tiles_per_batch + tile_of_cells(g, cell)) * g.SB + sub_of_cells(g, cell);
+    b = b < 0 ? 0 : (b >= B ? B - 1 : b);  // (the host layer rejects a batch vector that is not in [0, B))
+    if (g.owned) {
+        int pen[4];
+        const int k = owned_pencils(g, cell[1], cell[2], pen);
+        for (int q = 0; q < k; ++q) tiles[q] = (int)b * g.tiles_per_batch + pen[q] * g.np0 + cell[0];
+        return k;
+    }
+    tiles[0] = ((int)b * g.tiles_per_batch + tile_of_cells(g, cell)) * g.SB + sub_of_cells(g, cell);
+    return 1;
 }
 
 __global__ void __launch_bounds__(256) bin_count_kernel(Geom g, const float *__restrict__ pos,
                                                        const int64_t *__restrict__ batch, int64_t n, int64_t B,
                                                        int *__restrict__ count)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        atomicAdd(&count[point_tile(g, pos, batch, i, B)], 1);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int tiles[4];
+        const int k = point_tiles(g, pos, batch, i, B, tiles);
+        for (int q = 0; q < k; ++q) atomicAdd(&count[tiles[q]], 1);
+    }
 }
 
 __global__ void __launch_bounds__(256) bin_fill_kernel(Geom g, const float *__restrict__ pos,
@@ -69,10 +81,13 @@ __global__ void __launch_bounds__(256) bin_fill_kernel(Geom g, const float *__re
                                                       int *__restrict__ perm, float *__restrict__ spos)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int t = point_tile(g, pos, batch, i, B);
-        const int slot = offsets[t] + atomicAdd(&cursor[t], 1);
-        perm[slot] = (int)i;
-        for (int u = 0; u < g.dim; ++u) spos[(int64_t)slot * g.dim + u] = pos[i * g.dim + u];
+        int tiles[4];
+        const int k = point_tiles(g, pos, batch, i, B, tiles);
+        for (int q = 0; q < k; ++q) {
+            const int slot = offsets[tiles[q]] + atomicAdd(&cursor[tiles[q]], 1);
+            perm[slot] = (int)i;
+            for (int u = 0; u < g.dim; ++u) spos[(int64_t)slot * g.dim + u] = pos[i * g.dim + u];
+        }
     }
 }
 
@@ -90,8 +105,9 @@ __device__ __forceinline__ int pencil_of(const Geom &g, const int cell[3], int64
     return g.l1seg == 1 ? pencil : pencil * g.l1seg + (cell[0] / g.bin0) / g.l1bins;
 }
 
-// first-level bin of a point given by its (up to three) coordinates, internal axis order
-__device__ __forceinline__ int l1_bin_of(const Geom &g, float c0, float c1, float c2, int64_t b)
+// first-level bins of a point given by its (up to three) coordinates, internal axis order: one bin, or up to four
+// for the owned tiling (an entry per touched tile).  Returns the count.
+__device__ __forceinline__ int l1_bins_of(const Geom &g, float c0, float c1, float c2, int64_t b, int bins[4])
 {
     int cell[3] = {0, 0, 0};
     float fr;
@@ -105,7 +121,15 @@ __device__ __forceinline__ int l1_bin_of(const Geom &g, float c0, float c1, floa
     } else {
         split_cell(c0, g.M, cell[2], fr);
     }
-    return pencil_of(g, cell, b);
+    if (g.owned) {
+        int pen[4];
+        const int k = owned_pencils(g, cell[1], cell[2], pen);
+        const int seg = (cell[0] / g.bin0) / g.l1bins;
+        for (int q = 0; q < k; ++q) bins[q] = ((int)b * g.nta[1] * g.nta[2] + pen[q]) * g.l1seg + seg;
+        return k;
+    }
+    bins[0] = pencil_of(g, cell, b);
+    return 1;
 }
 
 // The first-level passes read kSortUnroll points per thread before touching the LDS counters: a wave then keeps
@@ -137,7 +161,9 @@ sort1_count_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restr
         for (int q = 0; q < kSortUnroll; ++q) {
             if (i0 + (int64_t)q * kSortThreads >= hi) continue;
             const int64_t b = bb[q] < 0 ? 0 : (bb[q] >= B ? B - 1 : bb[q]);
-            atomicAdd(&lds_hist[l1_bin_of(g, c0[q], c1[q], c2[q], b)], 1);
+            int bins[4];
+            const int k = l1_bins_of(g, c0[q], c1[q], c2[q], b, bins);
+            for (int r = 0; r < k; ++r) atomicAdd(&lds_hist[bins[r]], 1);
         }
     }
     __syncthreads();
@@ -170,8 +196,12 @@ sort1_scatter_kernel(Geom g, const float *__restrict__ pos, const int64_t *__res
             const int64_t i = i0 + (int64_t)q * kSortThreads;
             if (i >= hi) continue;
             const int64_t b = bb[q] < 0 ? 0 : (bb[q] >= B ? B - 1 : bb[q]);
-            const int slot = atomicAdd(&lds_cur[l1_bin_of(g, c0[q], c1[q], c2[q], b)], 1);
-            tmp[slot] = make_float4(c0[q], c1[q], c2[q], __int_as_float((int)i));
+            int bins[4];
+            const int k = l1_bins_of(g, c0[q], c1[q], c2[q], b, bins);
+            for (int r = 0; r < k; ++r) {
+                const int slot = atomicAdd(&lds_cur[bins[r]], 1);
+                tmp[slot] = make_float4(c0[q], c1[q], c2[q], __int_as_float((int)i));
+            }
         }
     }
 }
@@ -204,7 +234,9 @@ sort2_kernel(Geom g, int64_t n, int npencils, int nblocks, const int *__restrict
     const int nt0 = (min(g.np0, bin_lo + g.l1bins) - bin_lo) * g.SB;  // (axis-0 bin, sub-block) bins handled here
     const int64_t obase = ((int64_t)pencil * g.np0 + bin_lo) * g.SB;   // their first entry in the offsets table
     const int p0 = hscan[(int64_t)l1 * nblocks];
-    const int p1 = l1 + 1 < npencils ? hscan[(int64_t)(l1 + 1) * nblocks] : (int)n;
+    // (the scan has one item more than there are (bin, block) counts: its last entry is the number of plan entries,
+    // n for ordinary plans, larger for the owned tiling)
+    const int p1 = hscan[(int64_t)(l1 + 1) * nblocks];
     for (int i = threadIdx.x; i < nt0; i += kSortThreads) lds2[i] = 0;
     __syncthreads();
     // (eight records per thread in flight: a dense bin of a clustered input is one workgroup's serial loop)
@@ -238,7 +270,7 @@ sort2_kernel(Geom g, int64_t n, int npencils, int nblocks, const int *__restrict
             }
             carry += __shfl(incl, 63);
         }
-        if (l1 == npencils - 1 && threadIdx.x == 0) offsets[obase + nt0] = (int)n;
+        if (l1 == npencils - 1 && threadIdx.x == 0) offsets[obase + nt0] = p1;
     }
     __syncthreads();
     for (int j0 = p0 + threadIdx.x; j0 < p1; j0 += kSortThreads * 8) {
@@ -299,20 +331,23 @@ segment_split_kernel(Geom g, int npl /* point sets x pencils */, int runs, int t
     }
 }
 
-// xs[c, slot] = xr[perm[slot], c]  (tile-ordered, column-major copy of the real coefficient columns)
+// xs[c, slot] = xr[perm[slot], c]  (tile-ordered, column-major copy of the real coefficient columns; column stride
+// `stride` = plan capacity, `*total` = entries the plan holds)
 __global__ void __launch_bounds__(256) gather_rows_kernel(const int *__restrict__ perm, const float *__restrict__ xr,
-                                                         float *__restrict__ xs, int64_t n, int64_t cols)
+                                                         float *__restrict__ xs, const int *__restrict__ total_entries,
+                                                         int64_t stride, int64_t cols)
 {
+    const int64_t n = *total_entries;
     const int64_t total = n * cols;
     // eight elements per thread and step: first the eight permutation entries, then the eight (random) coefficient
     // reads, so that a wave has 8 x 64 independent loads in flight
     constexpr int UN = 8;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += stride * UN) {
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += step * UN) {
         int64_t src[UN];
 #pragma unroll
         for (int q = 0; q < UN; ++q) {
-            const int64_t e = e0 + q * stride;
+            const int64_t e = e0 + q * step;
             if (e < total) {
                 const int64_t slot = e / cols, c = e - slot * cols;
                 src[q] = (int64_t)perm[slot] * cols + c;
@@ -325,10 +360,10 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const int *__restrict_
         for (int q = 0; q < UN; ++q) v[q] = src[q] >= 0 ? xr[src[q]] : 0.0f;
 #pragma unroll
         for (int q = 0; q < UN; ++q) {
-            const int64_t e = e0 + q * stride;
+            const int64_t e = e0 + q * step;
             if (e < total) {
                 const int64_t slot = e / cols, c = e - slot * cols;
-                xs[c * n + slot] = v[q];
+                xs[c * stride + slot] = v[q];
             }
         }
     }
@@ -412,8 +447,10 @@ int launch_gather_rows(const Geom &g, const PlanLayout &L, const void *plan, int
                        float *xs, hipStream_t stream)
 {
     const int *perm = (const int *)((const char *)plan + L.off_perm);
+    const int *total = (const int *)((const char *)plan + L.off_offsets) + L.ntiles;  // offsets[ntiles] = entries
     if (n * cols > 0)
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n * cols, 256)), dim3(256), 0, stream, perm, xr, xs, n, cols);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(L.cap * cols, 256)), dim3(256), 0, stream, perm, xr, xs,
+                           total, L.cap, cols);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -36,9 +36,12 @@ struct TileCfg {
 // ~45x slower on gfx950, scripts/ubench/lds_ops.hip), which sets the budget NP * (T1+W-1) * (T2+W) * 8 B.
 // Wide tiling (MFMA spreading kernel, 3-D): the padded pencil is exactly one 32 x 64 accumulator tile pair,
 // T1 + W - 1 = 32 rows and T2 + W - 1 = 64 columns, and the plan is sorted by single planes ("slabs").
-constexpr TileCfg tile_cfg(int dim, int W, bool wide = false)
+// Owned tiling (owner-computes variant of the MFMA spreading kernel, sparse inputs): the accumulator tile IS the owned
+// region, T1 = 32, T2 = 64, and a point is entered into every tile its window touches (1, 2 or 4 plan entries).
+constexpr TileCfg tile_cfg(int dim, int W, bool wide = false, bool owned = false)
 {
-    return dim == 3 ? (wide ? TileCfg{33 - W, 65 - W, (W <= 16 ? 17 - W : 1) + W - 1, W <= 16 ? 17 - W : 1}
+    return dim == 3 ? (owned ? TileCfg{32, 64, (W <= 16 ? 17 - W : 1) + W - 1, W <= 16 ? 17 - W : 1}
+                     : wide ? TileCfg{33 - W, 65 - W, (W <= 16 ? 17 - W : 1) + W - 1, W <= 16 ? 17 - W : 1}
                      : W <= 12 ? TileCfg{16, 32, 16, 16 - (W - 1)}
                      : W <= 14 ? TileCfg{8, 32, 16, 16 - (W - 1)}
                                : TileCfg{8, 16, 20, 20 - (W - 1)})
@@ -72,6 +75,8 @@ struct Geom {
     int nta[3];   // tiles per internal axis (nta[0] = chunks)
     int nseg;     // segments per pencil
     int wide;     // wide (MFMA) tiling; the plan then has one bin per plane along axis 0
+    int owned;    // owned variant of the wide tiling: 32 x 64 tiles without halo, a point has an entry in every tile
+                  // its window touches (spreading by owner-computes: plain stores, no zero-fill, no atomics)
     int bin0;     // planes per plan bin along axis 0: Ta[0], or 1 for the wide tiling
     int np0;      // plan bins per pencil along axis 0
     int tiles_per_batch;  // plan bins per point set: np0 * nta[1] * nta[2]
@@ -84,7 +89,9 @@ struct Geom {
     int64_t cells; // M^dim
 };
 
-inline Geom make_geom(int dim, int64_t N, int64_t m)
+inline bool owned_supported(int dim, int64_t N, int64_t m);
+
+inline Geom make_geom(int dim, int64_t N, int64_t m, bool owned = false)
 {
     Geom g;
     g.dim = dim;
@@ -101,7 +108,9 @@ inline Geom make_geom(int dim, int64_t N, int64_t m)
     }
     // 16 waves hold 16 resident planes: the axis-0 window (2m+2 planes) has to fit
     g.wide = dim == 3 && spread_mode() == kSpreadMfma && g.M >= 64 && g.M <= 1024 && g.W <= 16;
-    const TileCfg tc = tile_cfg(dim, g.W, g.wide != 0);
+    // at least two tiles per axis, so that a window never touches the same tile from both sides of the torus
+    g.owned = owned && g.wide && g.M >= 128 && g.M % 64 == 0;
+    const TileCfg tc = tile_cfg(dim, g.W, g.wide != 0, g.owned != 0);
     g.Ta[0] = tc.TC;
     g.Ta[1] = tc.T1;
     g.Ta[2] = tc.T2;
@@ -123,6 +132,21 @@ inline Geom make_geom(int dim, int64_t N, int64_t m)
     g.sb2 = sub ? g.Ta[2] / kSub : 1;
     g.SB = g.sb1 * g.sb2;
     return g;
+}
+
+inline bool owned_supported(int dim, int64_t N, int64_t m) { return make_geom(dim, N, m, true).owned != 0; }
+
+// Sparse inputs take the owner-computes spreading kernel: below ~0.03 points per grid cell the atomic flush of the
+// padded tiles (and the zero-fill in front of it) costs more than spreading 1.46x as many plan entries
+// (measured crossover on MI355X; NFFT_HIP_OWNED=0 / 1 forces the choice).
+int owned_override();  // api.hip: -1 auto, 0 never, 1 whenever supported
+inline bool choose_owned(int dim, int64_t N, int64_t m, int64_t n, int64_t B)
+{
+    if (!owned_supported(dim, N, m)) return false;
+    const int ov = owned_override();
+    if (ov >= 0) return ov != 0;
+    const double cells = 8.0 * (double)N * (double)N * (double)N * (double)(B > 0 ? B : 1);
+    return n > 0 && (double)n < 0.03 * cells;
 }
 
 // ---- device helpers --------------------------------------------------------
@@ -186,6 +210,22 @@ __device__ __forceinline__ int tile_of_cells(const Geom &g, const int cell[3])
     return (j1 * g.nta[2] + j2) * g.np0 + k0;
 }
 
+// Owned tiling: the (up to four) pencils whose 32 x 64 tile the window of a point in cell (c1, c2) touches.
+// Returns their count; pencil index = j1 * nta[2] + j2.
+__device__ __forceinline__ int owned_pencils(const Geom &g, int c1, int c2, int pencil[4])
+{
+    const int a0 = wrap_near(c1 - g.m, g.M) / g.Ta[1], a1 = wrap_near(c1 + g.m + 1, g.M) / g.Ta[1];
+    const int b0 = wrap_near(c2 - g.m, g.M) / g.Ta[2], b1 = wrap_near(c2 + g.m + 1, g.M) / g.Ta[2];
+    int k = 0;
+    pencil[k++] = a0 * g.nta[2] + b0;
+    if (b1 != b0) pencil[k++] = a0 * g.nta[2] + b1;
+    if (a1 != a0) {
+        pencil[k++] = a1 * g.nta[2] + b0;
+        if (b1 != b0) pencil[k++] = a1 * g.nta[2] + b1;
+    }
+    return k;
+}
+
 // Point range of chunk k (Ta[0] planes) of a pencil: [s, e).  first_bin = index of the pencil's first plan bin.
 __device__ __forceinline__ void chunk_range(const Geom &g, const int *__restrict__ tile_offsets, int first_bin, int k,
                                             int &s, int &e)
@@ -244,6 +284,7 @@ struct DeviceOnce {
 };
 
 struct PlanLayout {
+    int64_t cap;  // entries the plan can hold: n, or 4 n for the owned tiling (an entry per touched tile)
     int64_t ntiles;
     int64_t npencils, nblocks;  // two-level sort geometry
     bool two_level;

@@ -18,6 +18,13 @@
 //     order, axis-0 table), one batch ahead of the MFMAs, in wave-sized tasks handed out through an LDS counter; the
 //     points themselves arrive by LDS-DMA two batches earlier.  Every owner whose plane lies in a K-block's window
 //     turns the psi1 rows into its A fragment (16 v_fma_mix) and issues 6 MFMAs.  One raw s_barrier per batch.
+// Owner-computes variant (template flag OWNED, plans of the owned tiling: sparse inputs, common.h choose_owned): the
+// 32 x 64 accumulator tile is the OWNED region of the grid -- a point has a plan entry in every tile its window
+// touches (1.46x entries at m = 4) and taps that fall outside the tile are masked -- and a work item owns the planes
+// [sb, se) of its tile: it sweeps the slabs [sb - m - 1, se + m) (cyclically) and writes every owned plane exactly
+// once with plain 128-byte row stores.  No zero-fill, no atomics, bitwise reproducible.  At low density the atomic
+// flush of the padded tiles is what the scatter variant spends its time on (1.3 TB/s chip-wide for float atomics
+// against ~6 TB/s for stores); at the density of config C3 it is not (profiles/r02_flush_variants.txt).
 // Why: ds_add_f32 is unusable on gfx950 and the f64 LDS atomic bounds spread.hip at ~3.7 ms for 1e10 taps
 // (DESIGN.md section 4); here the taps are 0.49 PFLOP of matrix work and the kernel runs 1.7 ms at C3.
 #include <algorithm>
@@ -36,7 +43,8 @@ constexpr int kKB = 16;        // points per K-block (the MFMA K dimension)
 constexpr int kNKB = 8;        // K-blocks per batch
 constexpr int kSlots = kKB * kNKB;
 constexpr int kMfmaThreads = 1024;
-constexpr int kMaxSegSlabs = 128;   // slabs of one work item (a range of M / runs slabs or a piece of it)
+constexpr int kMaxSegSlabs = 128;   // planes of one work item (a range of M / runs slabs or a piece of it)
+constexpr int kMaxSweep = kMaxSegSlabs + 2 * kMaxCutoff;  // slabs it sweeps: the owned variant adds 2m+1 halo slabs
 constexpr int kPsiStride = 20; // floats per row of the psi1 table (16 + 4: conflict-free ds_read_b128 over rows)
 
 // Operands of one batch of K-blocks, double-buffered: while the waves run the MFMAs of batch i they already build
@@ -84,13 +92,14 @@ struct __align__(16) MfmaLds {
     int raw_slab[2][kNKB];
     int task_counter[2];
     unsigned xmax_bits;                   // max |x| over the work item's points (bit pattern; staging of the f16 scale)
-    int2 sched[kMaxSegSlabs + 8];         // per slab: {K-blocks before it, point offset}; padded with the totals
+    int2 sched[kMaxSweep + 8];            // per slab: {K-blocks before it, point offset}; padded with the totals
+    int sched_end[kMaxSweep + 8];         // per slab: end of its point range
 };
 
-template <int W, bool OVERFLOW>
+template <int W, bool OVERFLOW, bool OWNED>
 __global__ void __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *__restrict__ spos,
-                   const float *__restrict__ xs, const int64_t n, const int Cr,
+                   const float *__restrict__ xs, const int64_t xs_stride, const int Cr,
                    const int plane0, float *__restrict__ grid, const int seg_slabs, const int nsegm,
                    const int *__restrict__ first_end, const int4 *__restrict__ overflow)
 {
@@ -131,15 +140,19 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     }
     const int j2 = pencil % g.nta[2];
     const int j1 = pencil / g.nta[2];
-    const int nslab = se - sb;
+    const int nplane = se - sb;  // planes (scatter variant: slabs) of this item
     const int bin0 = b * g.tiles_per_batch + pencil * g.np0;  // np0 == M: one plan bin per slab
-    if (nslab <= 0 || tile_offsets[bin0 + sb] == tile_offsets[bin0 + se]) continue;
+    if (nplane <= 0) continue;
+    if (!OWNED && tile_offsets[bin0 + sb] == tile_offsets[bin0 + se]) continue;
+    // slabs swept: [s_lo, s_lo + nslab), unwrapped; the owned variant reads the 2m+1 slabs around its planes as well
+    const int s_lo = OWNED ? sb - m - 1 : sb;
+    const int nslab = OWNED ? nplane + W - 1 : nplane;
 
     const int tb1 = j1 * g.Ta[1], tb2 = j2 * g.Ta[2];
     const float sc = win_exp_scale(m);
     float norm = win_norm(m);
     norm = norm * norm * norm;
-    const float *const xcol = xs + (int64_t)cr * n;
+    const float *const xcol = xs + (int64_t)cr * xs_stride;
     // x is scaled into [-1, 1] by a power of two so that every operand fits f16; undone at the flush.  The scale is
     // this work item's own: the largest |x| among the points of its slab range in its column -- columns, point sets or
     // regions of very different magnitude each keep their full ~22 bits (a single global scale would flush a column
@@ -148,8 +161,16 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     __syncthreads();
     {
         float mx = 0.0f;
-        const int p_end = tile_offsets[bin0 + se];
-        for (int j = tile_offsets[bin0 + sb] + tid; j < p_end; j += kMfmaThreads) mx = fmaxf(mx, fabsf(xcol[j]));
+        if (OWNED) {
+            for (int k = wave; k < nslab; k += kMfmaThreads / 64) {
+                const int sw = wrap(s_lo + k, g.M);
+                const int p_end = tile_offsets[bin0 + sw + 1];
+                for (int j = tile_offsets[bin0 + sw] + lane; j < p_end; j += 64) mx = fmaxf(mx, fabsf(xcol[j]));
+            }
+        } else {
+            const int p_end = tile_offsets[bin0 + se];
+            for (int j = tile_offsets[bin0 + sb] + tid; j < p_end; j += kMfmaThreads) mx = fmaxf(mx, fabsf(xcol[j]));
+        }
         for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
         // non-negative floats order like their bit patterns (inf saturates the scale, which is clamped below)
         if (lane == 0 && mx > 0.0f) atomicMax(&L.xmax_bits, __float_as_uint(mx));
@@ -175,14 +196,32 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     // full time instead of idling through the accumulation)
     constexpr int NOWN = W <= 12 ? 12 : 16;
     const bool owner = wave < NOWN;
-    int myz = (sb - m) + (((wave - (sb - m)) % NOWN) + NOWN) % NOWN;
+    const int z_lo = OWNED ? sb : sb - m;  // first plane any owner holds
+    int myz = z_lo + (((wave - z_lo) % NOWN) + NOWN) % NOWN;
     // staging threads: the first two non-owner waves if there are any, else waves 0 and 1
     constexpr int kStageWave0 = NOWN == 16 ? 0 : NOWN;
     const int st = tid - kStageWave0 * 64;  // slot of a staging thread, in [0, kSlots)
     const bool stager = (unsigned)st < (unsigned)kSlots;
 
     auto flush = [&]() {
-        if (dirty) {
+        if constexpr (OWNED) {
+            // every owned plane is written exactly once, whether or not points reached it
+            if (owner && myz >= sb && myz < se) {  // (the builder waves own nothing)
+                const float zscale = ((myz + m) & 1) ? -unscale : unscale;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float *const gcol = gplane + ((int64_t)myz * g.M + tb1) * g.M + tb2 + 32 * t + r32;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                        gcol[(int64_t)row * g.M] = (t == 0 ? acc0[reg] : acc1[reg]) * zscale;
+                    }
+                }
+            }
+            acc0 = 0.0f;
+            acc1 = 0.0f;
+            dirty = false;
+        } else if (dirty) {
             const int gz = wrap(myz, g.M);
             const float zscale = ((myz + m) & 1) ? -unscale : unscale;  // plane s - m + l0: parity of s + l0 + m
 #pragma unroll
@@ -206,25 +245,46 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
 
     // ---- K-block schedule: slab s holds ceil(count / 16) K-blocks; sched[s] = {K-blocks before s, point offset} ---
     if (wave == 0) {
-        const int s0 = 2 * lane, s1 = s0 + 1;
-        const int o0 = tile_offsets[bin0 + sb + min(s0, nslab)];
-        const int o1 = tile_offsets[bin0 + sb + min(s1, nslab)];
-        const int o2 = tile_offsets[bin0 + sb + min(s1 + 1, nslab)];
-        const int n0 = (o1 - o0 + kKB - 1) / kKB, n1 = (o2 - o1 + kKB - 1) / kKB;  // 0 beyond the segment
-        int incl = n0 + n1;
+        // three slabs per lane (up to kMaxSweep <= 192 slabs); slab k of the sweep is plan bin wrap(s_lo + k)
+        int ob[3], oe[3], nk[3];
+        int sum = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int k = 3 * lane + q;
+            const int sw = wrap(s_lo + min(k, nslab), g.M);
+            ob[q] = tile_offsets[bin0 + sw];
+            oe[q] = k < nslab ? tile_offsets[bin0 + sw + 1] : ob[q];
+            nk[q] = (oe[q] - ob[q] + kKB - 1) / kKB;  // 0 beyond the sweep
+            sum += nk[q];
+        }
+        int incl = sum;
         for (int off = 1; off < 64; off <<= 1) {
             const int t = __shfl_up(incl, off);
             if (lane >= off) incl += t;
         }
-        const int excl = incl - (n0 + n1);
-        L.sched[s0] = make_int2(excl, o0);
-        L.sched[s1] = make_int2(excl + n0, o1);
-        if (lane == 63)
-            for (int t = 0; t < 8; ++t) L.sched[kMaxSegSlabs + t] = make_int2(incl, o2);
+        int run = incl - sum;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int k = 3 * lane + q;
+            if (k < kMaxSweep + 8) {
+                L.sched[k] = make_int2(run, ob[q]);
+                L.sched_end[k] = oe[q];
+            }
+            run += nk[q];
+        }
+        // (entries at and beyond nslab hold the total: run == total there, and the probes below may read 4 past)
     }
     __syncthreads();
     const int total = L.sched[nslab].x;
     const int nbatch = (total + kNKB - 1) / kNKB;
+    if (OWNED && total == 0) {
+        // no points anywhere near these planes: they are still this item's to write
+        for (int e = tid; e < nplane * 512; e += kMfmaThreads) {
+            const int pz = e >> 9, row = (e >> 4) & 31, c4 = e & 15;
+            *(f32x4 *)(gplane + ((int64_t)(sb + pz) * g.M + tb1 + row) * g.M + tb2 + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        continue;
+    }
 
     // ---- staging of a batch: thread -> (K-block, point).  The points of batch i + 4 are requested (LDS-DMA into
     // L.raw[i & 1]) while batch i is accumulated and converted to (cell, fraction) form two steps later: under the
@@ -239,20 +299,20 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
         if (q < total) {
             // sched[lo].x <= q < sched[lo + 1].x; probe four slabs ahead per LDS round trip
             int lo = cur;
-            int2 e0, e1;
+            int2 e0;
             while (true) {
                 const int2 c0 = L.sched[lo], c1 = L.sched[lo + 1], c2 = L.sched[lo + 2], c3 = L.sched[lo + 3],
                            c4 = L.sched[lo + 4];
-                if (q < c1.x) { e0 = c0; e1 = c1; break; }
-                if (q < c2.x) { e0 = c1; e1 = c2; lo += 1; break; }
-                if (q < c3.x) { e0 = c2; e1 = c3; lo += 2; break; }
-                if (q < c4.x) { e0 = c3; e1 = c4; lo += 3; break; }
+                if (q < c1.x) { e0 = c0; break; }
+                if (q < c2.x) { e0 = c1; lo += 1; break; }
+                if (q < c3.x) { e0 = c2; lo += 2; break; }
+                if (q < c4.x) { e0 = c3; lo += 3; break; }
                 lo += 4;
             }
             cur = lo;
-            slab = sb + lo;
+            slab = s_lo + lo;  // unwrapped
             idx = e0.y + kKB * (q - e0.x) + i;
-            have = idx < e1.y;
+            have = idx < L.sched_end[lo];
             if (!have) idx = e0.y;  // any valid point: the value is not used
         }
         lds_dma_dword(spos + (int64_t)idx * 3 + 0, &L.raw[buf][0][(wave - kStageWave0) * 64]);
@@ -274,8 +334,17 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
             split_cell(L.raw[buf][0][st], g.M, c0, f0);
             split_cell(L.raw[buf][1][st], g.M, c1, f1);
             split_cell(L.raw[buf][2][st], g.M, c2, f2);
-            c1 -= tb1 - m;  // row of the point's cell inside the padded pencil (tap l1 sits at row c1 - m + l1)
-            c2 -= tb2 - m;
+            if constexpr (OWNED) {
+                // cell relative to the tile, in [-m - 1, T + m): tap l sits at row c1 - m + l1 of the (unpadded) tile
+                c1 -= tb1;
+                c2 -= tb2;
+                const int half = g.M >> 1;
+                c1 = c1 >= half ? c1 - g.M : (c1 < -half ? c1 + g.M : c1);
+                c2 = c2 >= half ? c2 - g.M : (c2 < -half ? c2 + g.M : c2);
+            } else {
+                c1 -= tb1 - m;  // row of the point's cell inside the padded pencil (tap l1 sits at row c1 - m + l1)
+                c2 -= tb2 - m;
+            }
             xv = L.raw[buf][3][st] * inv_xscale;
         }
         S.f0[st] = f0; S.f1[st] = f1; S.f2[st] = f2; S.x[st] = xv;
@@ -358,7 +427,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                 myz += NOWN;
             }
             const int l0 = myz - s + m;  // axis-0 tap of this K-block's points that lands on my plane
-            if ((unsigned)l0 < (unsigned)W) {
+            if ((unsigned)l0 < (unsigned)W && (!OWNED || myz < se)) {
                 const f32x4 *pp = (const f32x4 *)&O.psi1[j][r32][8 * h];
                 const f32x4 *pa = (const f32x4 *)&O.atab[j][l0][8 * h];
                 const f32x4 p0 = pp[0], p1 = pp[1], a0 = pa[0], a1 = pa[1];
@@ -409,6 +478,10 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     // the dummy requests of the last steps must have landed before the workgroup gives its LDS back
     if (stager) wait_lds_dma();
     flush();
+    if constexpr (OWNED) {
+        // owned planes behind the last slab that holds points
+        for (myz += NOWN; myz < se; myz += NOWN) flush();
+    }
     }  // work items
 }
 
@@ -416,7 +489,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
 
 bool spread_mfma_supported(const Geom &g) { return g.dim == 3 && g.wide; }
 
-template <int W>
+template <int W, bool OWNED>
 static int launch_mfma_t(const Geom &g, const PlanLayout &L, const void *plan, const int *to, const float *spos,
                          const float *xs, int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes,
                          float *grid, hipStream_t stream)
@@ -432,46 +505,59 @@ static int launch_mfma_t(const Geom &g, const PlanLayout &L, const void *plan, c
     const dim3 blocks((unsigned)(pencils * nsegm), (unsigned)nplanes);
     static DeviceOnce attr_done;  // one workgroup per CU: the double-buffered operands take most of the 160 KB LDS
     if (attr_done.first_use()) {
-        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)spread_mfma_kernel<W, false>,
+        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)spread_mfma_kernel<W, false, OWNED>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MfmaLds<W>)));
-        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)spread_mfma_kernel<W, true>,
+        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)spread_mfma_kernel<W, true, OWNED>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MfmaLds<W>)));
         attr_done.mark();
     }
     const char *base = (const char *)plan;
     const int *first_end = (const int *)(base + L.off_cursor);
-    hipLaunchKernelGGL((spread_mfma_kernel<W, false>), blocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to, spos,
-                       xs, n, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, (const int4 *)nullptr);
+    hipLaunchKernelGGL((spread_mfma_kernel<W, false, OWNED>), blocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to,
+                       spos, xs, L.cap, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, (const int4 *)nullptr);
     if (L.two_level) {
         // the pieces the plan cut off dense ranges (none for uniform inputs: the workgroups then leave at once)
         const int4 *overflow = (const int4 *)(base + L.off_tmp);
         const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
-        hipLaunchKernelGGL((spread_mfma_kernel<W, true>), oblocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to, spos,
-                           xs, n, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, overflow);
+        hipLaunchKernelGGL((spread_mfma_kernel<W, true, OWNED>), oblocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g,
+                           to, spos, xs, L.cap, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, overflow);
     }
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, const float *xs,
-                       int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream)
+template <bool OWNED>
+static int launch_mfma_w(const Geom &g, const PlanLayout &L, const void *plan, const float *xs, int64_t n, int64_t Cr,
+                         int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream)
 {
     const char *base = (const char *)plan;
     const int *to = (const int *)(base + L.off_offsets);
     const float *spos = (const float *)(base + L.off_spos);
-    if (nplanes <= 0 || n <= 0) return 0;
     switch (g.m) {
-    case 1: return launch_mfma_t<4>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 2: return launch_mfma_t<6>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 3: return launch_mfma_t<8>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 4: return launch_mfma_t<10>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 5: return launch_mfma_t<12>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 6: return launch_mfma_t<14>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 7: return launch_mfma_t<16>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 8: return launch_mfma_t<18>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 1: return launch_mfma_t<4, OWNED>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 2: return launch_mfma_t<6, OWNED>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 3: return launch_mfma_t<8, OWNED>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 4: return launch_mfma_t<10, OWNED>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 5: return launch_mfma_t<12, OWNED>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 6: return launch_mfma_t<14, OWNED>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 7: return launch_mfma_t<16, OWNED>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
     }
-    set_error("cutoff m must be in 1..8");
+    set_error("matrix-core spreading supports cutoff 1..7");
     return 1;
+}
+
+// `n` is the problem's point count (it fixes the work decomposition the plan was built for); the plan may hold more
+// entries than that (owned tiling).  The owned variant writes every cell of the planes: no zero-fill needed.
+int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, const float *xs,
+                       int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream)
+{
+    if (nplanes <= 0) return 0;
+    if (n <= 0) {
+        if (g.owned) NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(nplanes * g.cells * 4), stream));
+        return 0;
+    }
+    return g.owned ? launch_mfma_w<true>(g, L, plan, xs, n, Cr, plane0, nplanes, grid, stream)
+                   : launch_mfma_w<false>(g, L, plan, xs, n, Cr, plane0, nplanes, grid, stream);
 }
 
 } // namespace nfft
