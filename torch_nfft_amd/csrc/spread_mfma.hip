@@ -338,9 +338,9 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                 // cell relative to the tile, in [-m - 1, T + m): tap l sits at row c1 - m + l1 of the (unpadded) tile
                 c1 -= tb1;
                 c2 -= tb2;
-                const int half = g.M >> 1;
-                c1 = c1 >= half ? c1 - g.M : (c1 < -half ? c1 + g.M : c1);
-                c2 = c2 >= half ? c2 - g.M : (c2 < -half ? c2 + g.M : c2);
+                // (periodic image whose window reaches the tile: offsets in [-m - 1, T + m); M >= 128 keeps it unique)
+                c1 = c1 >= 32 + m ? c1 - g.M : (c1 < -(m + 1) ? c1 + g.M : c1);
+                c2 = c2 >= 64 + m ? c2 - g.M : (c2 < -(m + 1) ? c2 + g.M : c2);
             } else {
                 c1 -= tb1 - m;  // row of the point's cell inside the padded pencil (tap l1 sits at row c1 - m + l1)
                 c2 -= tb2 - m;
