@@ -34,7 +34,7 @@ extern "C" {
 #define NFFT_HIP_EFFT 3       /* rocFFT plan creation/execution failed (reference: "Failed to create CUFFT plan", core_cuda.cu:255-268) */
 #define NFFT_HIP_EHIP 4       /* HIP runtime error (reference aborts the process, cuda_utils.cu:7-14; we report) */
 
-#define NFFT_HIP_ABI_VERSION 1
+#define NFFT_HIP_ABI_VERSION 2
 
 int nfft_hip_abi_version(void);
 const char *nfft_hip_last_error(void);
@@ -46,9 +46,15 @@ const char *nfft_hip_last_error(void);
  *   num_columns   x.numel() / num_points  resp.  x.numel() / (B * N^dim)   (core_cuda.cu:84, 108-113)
  *   batch_size    batch[-1] + 1, or 1 when batch is NULL  (core_cuda.cu:60-65) -- read back by the HOST side
  *   N             bandwidth (even, >= 2);  m  window cutoff, 1 <= m, 2m+2 <= 2N
+ *   flags         hints about the point geometry (0 = none).  They never change results, only which kernels run; a
+ *                 point plan must be used with the flags it was built with.
  */
+#define NFFT_HIP_POINTS_IN_QUARTER_BALL 1 /* every point lies within radius 1/4 of the origin -- the fastsum geometry
+                                           * (test/test_fastsum.py:17-18, torch_nfft/kernel.py:77): the points occupy at
+                                           * most 1/8 of the grid, so their local density is 8x the average */
 typedef struct nfft_hip_problem {
     int32_t dim;
+    int32_t flags;
     int64_t num_points;
     int64_t num_columns;
     int64_t batch_size;
@@ -144,6 +150,8 @@ int nfft_hip_fastsum(const nfft_hip_problem *src, const float *sources, const in
                      const nfft_hip_problem *tgt, const float *targets, const int64_t *target_batch, const void *x,
                      int x_is_complex, const void *coeffs, int coeffs_are_complex, void *y, void *workspace,
                      int64_t workspace_bytes, void *stream);
+/* (The fastsum drivers treat both point sets as NFFT_HIP_POINTS_IN_QUARTER_BALL whatever `flags` says: plans handed
+ * to the _planned variant must have been built with that flag set.) */
 int nfft_hip_fastsum_planned(const nfft_hip_problem *src, const void *source_plan, const nfft_hip_problem *tgt,
                              const void *target_plan, const void *x, int x_is_complex, const void *coeffs,
                              int coeffs_are_complex, void *y, void *workspace, int64_t workspace_bytes, void *stream);

@@ -655,3 +655,35 @@ print("RESULT", err, bool((y == y2).all()))
     assert float(line[1]) < T2[4]
     if owned == "1":
         assert line[2] == "True"  # no atomics: bitwise reproducible
+
+
+# ----------------------------------------------------------------------------- wave-per-column interpolation
+
+@pytest.mark.parametrize("C,complex_out,chunk_planes", [(5, True, None), (3, False, None), (9, False, 7), (4, True, 5)])
+def test_forward_many_columns_wave_per_column(tn, monkeypatch, C, complex_out, chunk_planes):
+    """From 4 real planes per point set the forward gather runs one wave per column (interp_cols.hip): column counts
+    that do not fill the last group of 8, chunks of planes that start in the middle of a group and of a point set,
+    a pencil holding far more than one group of 384 points (several plane sweeps), empty point sets, points on the
+    torus boundary -- forward transform against the float64 algorithm restatement, per column."""
+    rng = np.random.default_rng(600 + C)
+    N, m, B = 32, 4, 4
+    n_dense, n_rest = 6000, 3000
+    dense = (0.02 * rng.standard_normal((n_dense, 3)) + np.array([0.11, -0.23, 0.37])).astype(np.float32)
+    edge = np.array([[-0.5, -0.5, -0.5], [0.49999997, 0.49999997, 0.49999997], [0.0, 0.0, 0.0]], np.float32)
+    pos = np.concatenate([dense, edge, (rng.random((n_rest, 3)) - 0.5).astype(np.float32)]).astype(np.float32)
+    n = pos.shape[0]
+    batch = np.sort(rng.choice([0, 1, 3], size=n)).astype(np.int64)  # point set 2 is empty
+    batch[0], batch[-1] = 0, 3
+    pos = pos[rng.permutation(n)]
+    shape = (B, N, N, N, C)
+    xh = rng.standard_normal(shape).astype(np.float32)
+    if complex_out:
+        xh = (xh + 1j * rng.standard_normal(shape)).astype(np.complex64)
+    if chunk_planes is not None:
+        monkeypatch.setenv("NFFT_HIP_CHUNK_BYTES", str(chunk_planes * (64 ** 3 * 4 + 64 * 64 * 33 * 8) + 8))
+    y = host(tn.nfft_forward(dev(xh), dev(pos), dev(batch), cutoff=m, real_output=not complex_out))
+    ref = nfft_ref.nfft_forward(xh, pos, batch, m=m, real_output=not complex_out)
+    assert y.shape == (n, C)
+    for c in range(C):
+        assert rel_l2(y[:, c], ref[:, c]) < T1, c
+    assert rel_l2(y, ref) < 2e-6

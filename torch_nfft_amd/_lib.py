@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NFFT_HIP_LIB") or os.path.join(_HERE, "libnfft_hip.so")
 CORE_PATH = os.path.join(_HERE, "core.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
+POINTS_IN_QUARTER_BALL = 1
 
 # every symbol include/nfft_hip.h declares
 SYMBOLS = (
@@ -50,12 +51,17 @@ class Problem(ctypes.Structure):
     """``nfft_hip_problem`` of include/nfft_hip.h."""
     _fields_ = [
         ("dim", ctypes.c_int32),
+        ("flags", ctypes.c_int32),
         ("num_points", ctypes.c_int64),
         ("num_columns", ctypes.c_int64),
         ("batch_size", ctypes.c_int64),
         ("N", ctypes.c_int64),
         ("m", ctypes.c_int64),
     ]
+
+
+    def __init__(self, dim=0, num_points=0, num_columns=0, batch_size=1, N=0, m=0, flags=0):
+        super().__init__(dim, flags, num_points, num_columns, batch_size, N, m)
 
 
 _lib = None

@@ -131,7 +131,8 @@ PlanSet plan_set(const nfft_hip_problem *p)
     PlanSet ps;
     ps.g = make_geom(p->dim, p->N, p->m);
     ps.L = plan_layout(ps.g, p->num_points, p->batch_size);
-    ps.owned = choose_owned(p->dim, p->N, p->m, p->num_points, p->batch_size);
+    ps.owned = choose_owned(p->dim, p->N, p->m, p->num_points, p->batch_size,
+                            (p->flags & NFFT_HIP_POINTS_IN_QUARTER_BALL) ? 0.125 : 1.0);
     ps.go = ps.g;
     ps.Lo = ps.L;
     ps.off_own = 0;
@@ -151,7 +152,8 @@ int build_plans(const PlanSet &ps, const float *pos, const int64_t *batch, int64
     return 0;
 }
 
-// interpolation: matrix-core kernel for the wide 3-D tiling unless NFFT_HIP_GATHER=lds
+// interpolation: matrix-core kernels for the wide 3-D tiling (the wave-per-column one from 4 real columns up) unless
+// NFFT_HIP_GATHER=lds (lane-per-point kernel) or =mfma (always the plane-ring kernel)
 int gather_any(const Geom &g, const PlanLayout &L, const void *plan, const float *grid, int64_t n, int64_t Cr,
                int64_t plane0, int64_t nplanes, float *yr, hipStream_t s)
 {
@@ -159,6 +161,7 @@ int gather_any(const Geom &g, const PlanLayout &L, const void *plan, const float
         const char *env = std::getenv("NFFT_HIP_GATHER");
         return env && env[0] == 'l';
     }();
+    if (!lds_only && interp_cols_supported(g, Cr)) return launch_interp_cols(g, L, plan, grid, n, Cr, plane0, nplanes, yr, s);
     if (!lds_only && interp_mfma_supported(g)) return launch_interp_mfma(g, L, plan, grid, n, Cr, plane0, nplanes, yr, s);
     return launch_interp(g, L, plan, grid, n, Cr, plane0, nplanes, yr, s);
 }
@@ -558,11 +561,18 @@ int fastsum_carve(const nfft_hip_problem *src, const nfft_hip_problem *tgt, int 
     f.total = o + 256;
     return 0;
 }
-int fastsum_impl(const nfft_hip_problem *src, const float *sources, const int64_t *source_batch, const void *source_plan,
-                 const nfft_hip_problem *tgt, const float *targets, const int64_t *target_batch, const void *target_plan,
-                 const void *x, int x_is_complex, const void *coeffs, int coeffs_are_complex, void *y, void *workspace,
-                 int64_t workspace_bytes, void *stream)
+int fastsum_impl(const nfft_hip_problem *src_in, const float *sources, const int64_t *source_batch,
+                 const void *source_plan, const nfft_hip_problem *tgt_in, const float *targets,
+                 const int64_t *target_batch, const void *target_plan, const void *x, int x_is_complex,
+                 const void *coeffs, int coeffs_are_complex, void *y, void *workspace, int64_t workspace_bytes,
+                 void *stream)
 {
+    if (!src_in || !tgt_in) { set_error("Input mismatch: null problem"); return NFFT_HIP_EINVAL; }
+    // fastsum geometry: every point within radius 1/4 (the kernel is only defined there)
+    nfft_hip_problem src_q = *src_in, tgt_q = *tgt_in;
+    src_q.flags |= NFFT_HIP_POINTS_IN_QUARTER_BALL;
+    tgt_q.flags |= NFFT_HIP_POINTS_IN_QUARTER_BALL;
+    const nfft_hip_problem *src = &src_q, *tgt = &tgt_q;
     if (int rc = fastsum_check(src, tgt)) return rc;
     const bool own_plans = source_plan == nullptr;
     const bool shared = own_plans ? (sources == targets && source_batch == target_batch && src->num_points == tgt->num_points)
@@ -608,9 +618,13 @@ int fastsum_impl(const nfft_hip_problem *src, const float *sources, const int64_
 int64_t nfft_hip_fastsum_workspace_bytes(const nfft_hip_problem *src, const nfft_hip_problem *tgt, int x_is_complex,
                                          int shared_points, int planned)
 {
-    if (fastsum_check(src, tgt)) return -1;
+    if (!src || !tgt) return -1;
+    nfft_hip_problem s = *src, t = *tgt;
+    s.flags |= NFFT_HIP_POINTS_IN_QUARTER_BALL;
+    t.flags |= NFFT_HIP_POINTS_IN_QUARTER_BALL;
+    if (fastsum_check(&s, &t)) return -1;
     FastsumCarve f;
-    if (fastsum_carve(src, tgt, x_is_complex, planned == 0, shared_points != 0, f)) return -1;
+    if (fastsum_carve(&s, &t, x_is_complex, planned == 0, shared_points != 0, f)) return -1;
     return f.total;
 }
 

@@ -140,12 +140,14 @@ inline bool owned_supported(int dim, int64_t N, int64_t m) { return make_geom(di
 // padded tiles (and the zero-fill in front of it) costs more than spreading 1.46x as many plan entries
 // (measured crossover on MI355X; NFFT_HIP_OWNED=0 / 1 forces the choice).
 int owned_override();  // api.hip: -1 auto, 0 never, 1 whenever supported
-inline bool choose_owned(int dim, int64_t N, int64_t m, int64_t n, int64_t B)
+// `occupied`: fraction of the grid the points are known to live in (1/8 for the fastsum geometry, else 1): what
+// counts is the density where the points are.
+inline bool choose_owned(int dim, int64_t N, int64_t m, int64_t n, int64_t B, double occupied)
 {
     if (!owned_supported(dim, N, m)) return false;
     const int ov = owned_override();
     if (ov >= 0) return ov != 0;
-    const double cells = 8.0 * (double)N * (double)N * (double)N * (double)(B > 0 ? B : 1);
+    const double cells = 8.0 * (double)N * (double)N * (double)N * (double)(B > 0 ? B : 1) * occupied;
     return n > 0 && (double)n < 0.03 * cells;
 }
 

@@ -83,10 +83,11 @@ bool real_dtype(const at::Tensor &t)
     return false;
 }
 
-nfft_hip_problem problem(const Points &p, int64_t C, int64_t N, int64_t m)
+nfft_hip_problem problem(const Points &p, int64_t C, int64_t N, int64_t m, int32_t flags = 0)
 {
     nfft_hip_problem q;
     q.dim = p.dim;
+    q.flags = flags;
     q.num_points = p.n;
     q.num_columns = C;
     q.batch_size = p.B;
@@ -107,12 +108,12 @@ nfft_hip_problem problem(const Points &p, int64_t C, int64_t N, int64_t m)
 struct PlanKey {
     const void *pos_ptr = nullptr, *batch_ptr = nullptr;
     int64_t pos_version = -1, batch_version = -1, n = -1, B = -1, N = -1, m = -1;
-    int dim = 0, device = -1;
+    int dim = 0, device = -1, flags = 0;  // (a plan is only valid for the geometry hints it was built with)
     bool operator==(const PlanKey &o) const
     {
         return pos_ptr == o.pos_ptr && batch_ptr == o.batch_ptr && pos_version == o.pos_version &&
                batch_version == o.batch_version && n == o.n && B == o.B && N == o.N && m == o.m && dim == o.dim &&
-               device == o.device;
+               device == o.device && flags == o.flags;
     }
 };
 struct PlanEntry {
@@ -146,6 +147,7 @@ at::Tensor get_plan(const Points &p, const nfft_hip_problem &q)
     key.batch_ptr = p.batch.defined() ? p.batch.data_ptr() : nullptr;
     key.batch_version = p.batch.defined() ? (int64_t)p.batch._version() : -1;
     key.n = p.n; key.B = p.B; key.N = q.N; key.m = q.m; key.dim = p.dim; key.device = p.pos.device().index();
+    key.flags = q.flags;
     std::lock_guard<std::mutex> lock(g_cache.mutex);
     if (g_cache.enabled) {
         for (PlanEntry &e : g_cache.entries) {
@@ -298,7 +300,8 @@ at::Tensor nfft_fastsum(at::Tensor sources, at::Tensor targets, at::Tensor x, at
     at::Tensor y = at::empty(shape, x.options());  // same dtype as x (core_cuda.cu:817-821)
     if (y.numel() == 0) return y;
     const at::Tensor xc = x.contiguous(), cc = coeffs.contiguous();
-    const nfft_hip_problem qs = problem(ps, C, N, m), qt = problem(pt, C, N, m);
+    const nfft_hip_problem qs = problem(ps, C, N, m, NFFT_HIP_POINTS_IN_QUARTER_BALL),
+                           qt = problem(pt, C, N, m, NFFT_HIP_POINTS_IN_QUARTER_BALL);
     c10::DeviceGuard guard(x.device());
     const int64_t ws_bytes = nfft_hip_fastsum_workspace_bytes(&qs, &qt, real_input ? 0 : 1, shared ? 1 : 0, 1);
     if (ws_bytes < 0) check_rc(std::string(nfft_hip_last_error()).rfind("Input mismatch", 0) == 0 ? NFFT_HIP_EINVAL : NFFT_HIP_EFFT);

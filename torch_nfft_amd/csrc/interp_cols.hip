@@ -1,0 +1,359 @@
+// Interpolation (forward gather) for several coefficient columns: one wave per column ("wave = column").
+//
+// Same result as interp_mfma.hip / the reference's forward_window_convolution kernels
+// (csrc/cuda/spatial_window_operations.cu:214-332); the reference loops over the trailing columns inside its
+// kernel (":281-330") re-using shift and psi of a point for every column.  Here the sharing is:
+//   * a workgroup of 8 waves takes one work item of the wide tiling (point set, pencil, range of slabs) for 8
+//     consecutive grid planes of that point set -- 8 real coefficient columns; wave w owns column w;
+//   * what depends only on the POINTS is built once per block of 32 points and shared through LDS by all 8
+//     columns: the B fragments (psi2 on the 64 padded columns, f16-split, in MFMA register order), the 16 psi1
+//     weights per lane, the cell / fraction along axis 0 -- in interp_mfma.hip every (set, column) plane has its
+//     own workgroup and rebuilds them (64 x at config C4);
+//   * what depends on the COLUMN never touches LDS: each wave streams the padded 32 x 64 tile of its own column's
+//     plane straight from global memory into A-fragment registers (eight 16-byte loads per lane, the next plane
+//     prefetched while the current one is used), scales it by the tile's power of two and splits it into f16
+//     hi / lo in registers.  No staging phases, no barrier inside the plane sweep;
+//   * per plane z and active block:  T_z = G_z Psi2 (12 MFMAs), t = sum_u1 psi1[u1] T_z[u1, i], y_i += psi0_i[z] t
+//     exactly as in interp_mfma.hip; a wave keeps one y accumulator per block of the group in registers.
+// Blocks are handled in groups of kIcBlocks (what fits the LDS); a group's plane sweep runs from the first
+// point's window to the last one's, so a sparse item (config C4: 6.5 points per slab and pencil) sweeps its
+// planes ~1.2 times, a dense one more often -- the kernel is chosen for multi-column problems, where the column
+// sharing pays for that (api.hip gather_any).
+// The results leave through LDS: 8 columns of a point are 32 contiguous bytes of y.
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "kernels.h"
+#include "mfma_split.h"
+
+namespace nfft {
+
+namespace {
+
+constexpr int kIcWaves = 8;                 // columns per workgroup
+constexpr int kIcThreads = kIcWaves * 64;
+constexpr int kIcBlocks = 12;               // blocks of 32 points resident at a time
+
+struct __align__(16) IcLds {
+    f16x8 bfrag[kIcBlocks][4][2][64];       // [block][k-step][hi/lo][lane = 32 (column half) + point]   96 KB
+    f32x4 w1[kIcBlocks][4][64];             // [block][register quad][lane]: psi1 of the lane's point on its 16 rows  48 KB
+    float f0[kIcBlocks][32];                // fraction along axis 0
+    int c0[kIcBlocks][32];                  // cell along axis 0 (unwrapped slab), INT_MIN/2 for padding lanes
+    int zf[kIcBlocks], zl[kIcBlocks];       // first / last plane of the block's window
+};
+// after a group's sweep the fragment area is reused to transpose the results: [point of the group][column]
+constexpr int kIcStageStride = kIcWaves + 1;
+static_assert(kIcBlocks * 32 * kIcStageStride * 4 <= (int)sizeof(f16x8) * kIcBlocks * 4 * 2 * 64, "stage fits");
+
+template <int W, bool OVERFLOW>
+__global__ void __launch_bounds__(kIcThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__restrict__ perm,
+                   const float *__restrict__ spos, const float *__restrict__ grid, const int Cr, const int64_t plane0,
+                   const int64_t nplanes, const int64_t group0, float *__restrict__ yr, const int seg_slabs,
+                   const int nsegm, const int *__restrict__ first_end, const int4 *__restrict__ overflow)
+{
+    constexpr int m = W / 2 - 1;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    IcLds &L = *reinterpret_cast<IcLds *>(smem_raw);
+    float *const ystage = reinterpret_cast<float *>(&L.bfrag[0][0][0][0]);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, h = lane >> 5;
+
+    // column group -> (point set, first column); wave -> plane
+    const int G = (Cr + kIcWaves - 1) / kIcWaves;
+    const int64_t gid = group0 + blockIdx.y;
+    const int b = (int)(gid / G);
+    const int cr0 = (int)(gid - (int64_t)b * G) * kIcWaves;
+    const int cr = cr0 + wave;
+    const int64_t plane = (int64_t)b * Cr + cr;
+    const bool col_active = cr < Cr && plane >= plane0 && plane < plane0 + nplanes;  // wave-uniform
+    const float *const gplane = grid + (plane - plane0) * g.cells;  // (only dereferenced when col_active)
+    const int pencils = g.nta[1] * g.nta[2];
+    const int M = g.M;
+
+    const int n_items = OVERFLOW ? overflow[0].x : 1;
+    for (int item = OVERFLOW ? (int)blockIdx.x : 0; item < n_items; item += OVERFLOW ? (int)gridDim.x : 1) {
+    int pencil, sb, se;
+    if constexpr (OVERFLOW) {
+        const int4 it = overflow[1 + item];
+        if (it.x / pencils != b) continue;  // another point set's piece
+        pencil = it.x % pencils;
+        sb = it.y;
+        se = it.z;
+    } else {
+        pencil = blockIdx.x / nsegm;
+        const int seg = blockIdx.x % nsegm;
+        sb = min(seg * seg_slabs, M);
+        se = sb < M ? first_end[(int64_t)(b * pencils + pencil) * kSegMax + seg] : sb;
+    }
+    if (se <= sb) continue;
+    const int bin0 = b * g.tiles_per_batch + pencil * g.np0;  // one plan bin per slab
+    const int p_begin = tile_offsets[bin0 + sb], p_end = tile_offsets[bin0 + se];
+    if (p_begin == p_end) continue;
+    const int j2 = pencil % g.nta[2], j1 = pencil / g.nta[2];
+    const int tb1 = j1 * g.Ta[1], tb2 = j2 * g.Ta[2];
+    const float sc = win_exp_scale(m);
+    float norm = win_norm(m);
+    norm = norm * norm * norm;
+
+    // row of this lane inside the plane and its eight 8-column pieces (two 16-byte loads each)
+    const int64_t grow_off = (int64_t)wrap_near(tb1 - m + r32, M) * M;
+    const int ccol0 = tb2 - m + 8 * h;  // + 16 ks
+    const bool fast_cols = tb2 - m >= 0 && tb2 - m + 64 <= M;  // no periodic wrap inside the padded columns
+
+    auto load_tile = [&](const int z, f32x4 (&raw)[8]) {
+        const float *const prow = gplane + (int64_t)wrap(z, M) * M * M + grow_off;
+        if (fast_cols) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                raw[2 * ks] = *(const f32x4 *)(prow + ccol0 + 16 * ks);
+                raw[2 * ks + 1] = *(const f32x4 *)(prow + ccol0 + 16 * ks + 4);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int c = ccol0 + 16 * ks + 4 * e;
+                    f32x4 v;
+                    v.x = prow[wrap_near(c, M)];
+                    v.y = prow[wrap_near(c + 1, M)];
+                    v.z = prow[wrap_near(c + 2, M)];
+                    v.w = prow[wrap_near(c + 3, M)];
+                    raw[2 * ks + e] = v;
+                }
+            }
+        }
+    };
+
+    for (int c_begin = p_begin; c_begin < p_end; c_begin += kIcBlocks * 32) {
+        const int npts = min(kIcBlocks * 32, p_end - c_begin);
+        const int nblk = (npts + 31) >> 5;
+        __syncthreads();  // the previous group's results have left the staging area
+
+        // ---- shared tables of the group's blocks: wave w builds blocks w, w + 8 ----------------------------------
+        for (int j = wave; j < nblk; j += kIcWaves) {
+            const int pt = c_begin + 32 * j + r32;
+            const bool valid = pt < p_end;
+            int c0 = 0, c1 = 0, c2 = 0;
+            float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+            if (valid) {
+                split_cell(spos[(int64_t)pt * 3 + 0], M, c0, f0);
+                split_cell(spos[(int64_t)pt * 3 + 1], M, c1, f1);
+                split_cell(spos[(int64_t)pt * 3 + 2], M, c2, f2);
+            }
+            const int nvalid = min(32, p_end - (c_begin + 32 * j));
+            const int zf = __builtin_amdgcn_readlane(c0, 0) - m;
+            const int zl = __builtin_amdgcn_readlane(c0, nvalid - 1) + m + 1;
+            if (lane == 0) { L.zf[j] = zf; L.zl[j] = zl; }
+            if (h == 0) {
+                L.f0[j][r32] = f0;
+                L.c0[j][r32] = valid ? c0 : -(1 << 28);  // padding lanes: outside every window
+            }
+            // B fragments: psi2 of my point on the padded columns 16 ks + 8 h + jj (zero outside the window)
+            const int o2 = c2 - tb2;  // padded column of tap 0
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                float w[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int l2 = 16 * ks + 8 * h + jj - o2;
+                    const float d = f2 + (float)(m - l2);
+                    const float ev = __builtin_amdgcn_exp2f(sc * d * d) * kOpScale;
+                    w[jj] = (valid && (unsigned)l2 < (unsigned)W) ? ev : 0.0f;
+                }
+                unsigned h0, h1, h2, h3, q0, q1, q2, q3;
+                split_pair(w[0], w[1], h0, q0);
+                split_pair(w[2], w[3], h1, q1);
+                split_pair(w[4], w[5], h2, q2);
+                split_pair(w[6], w[7], h3, q3);
+                L.bfrag[j][ks][0][lane] = __builtin_bit_cast(f16x8, u32x4{h0, h1, h2, h3});
+                L.bfrag[j][ks][1][lane] = __builtin_bit_cast(f16x8, u32x4{q0, q1, q2, q3});
+            }
+            // psi1 of my point on the 16 rows this lane holds of every T_z (MFMA result layout)
+            const int o1 = c1 - tb1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float wv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = r + 8 * q + 4 * h;
+                    const int l1 = row - o1;
+                    const float d = f1 + (float)(m - l1);
+                    const float ev = __builtin_amdgcn_exp2f(sc * d * d);
+                    wv[r] = (valid && (unsigned)l1 < (unsigned)W) ? ev : 0.0f;
+                }
+                L.w1[j][q][lane] = f32x4{wv[0], wv[1], wv[2], wv[3]};
+            }
+        }
+        __syncthreads();
+
+        // ---- plane sweep of this wave's column -------------------------------------------------------------------
+        float yacc[kIcBlocks];
+#pragma unroll
+        for (int j = 0; j < kIcBlocks; ++j) yacc[j] = 0.0f;
+        if (col_active) {
+            const int z_first = L.zf[0], z_last = L.zl[nblk - 1];
+            // windows of the blocks, wave-uniform: lane j holds block j's
+            const int zf_l = lane < nblk ? L.zf[lane] : (1 << 28);
+            const int zl_l = lane < nblk ? L.zl[lane] : -(1 << 28);
+            f32x4 raw[8], nxt[8];
+            load_tile(z_first, raw);
+            for (int z = z_first; z <= z_last; ++z) {
+                if (z < z_last) load_tile(z + 1, nxt);
+                // power-of-two scale: max |G| of the tile lands in [1024, 2048); odd planes enter negated (the MFMA
+                // accumulation truncates with a small sign-independent bias that cancels over alternating planes)
+                float mx = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    mx = fmaxf(fmaxf(fmaxf(mx, fabsf(raw[e].x)), fabsf(raw[e].y)), fmaxf(fabsf(raw[e].z), fabsf(raw[e].w)));
+                for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+                if (mx > 0.0f) {  // (an all-zero tile adds nothing)
+                    float scale = 1.0f, pinv = 1.0f / kOpScale;
+                    if (mx > 1.0e-30f && mx < 3.0e38f) {
+                        int ex;
+                        frexpf(mx, &ex);
+                        scale = ldexpf(1.0f, 11 - ex);
+                        pinv = ldexpf(1.0f, ex - 11) * (1.0f / kOpScale);
+                    }
+                    if (z & 1) { scale = -scale; pinv = -pinv; }
+                    u32x4 ah[4], al[4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const f32x4 a = raw[2 * ks], c = raw[2 * ks + 1];
+                        unsigned h0, h1, h2, h3, q0, q1, q2, q3;
+                        split_pair(a.x * scale, a.y * scale, h0, q0);
+                        split_pair(a.z * scale, a.w * scale, h1, q1);
+                        split_pair(c.x * scale, c.y * scale, h2, q2);
+                        split_pair(c.z * scale, c.w * scale, h3, q3);
+                        ah[ks] = u32x4{h0, h1, h2, h3};
+                        al[ks] = u32x4{q0, q1, q2, q3};
+                    }
+#pragma unroll
+                    for (int j = 0; j < kIcBlocks; ++j) {
+                        const int zf = __builtin_amdgcn_readlane(zf_l, j), zl = __builtin_amdgcn_readlane(zl_l, j);
+                        if (z < zf || z > zl) continue;  // wave-uniform
+                        f32x16 acc = 0.0f;
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            const f16x8 bh = L.bfrag[j][ks][0][lane], bl = L.bfrag[j][ks][1][lane];
+                            const f16x8 ahk = __builtin_bit_cast(f16x8, ah[ks]), alk = __builtin_bit_cast(f16x8, al[ks]);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahk, bh, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahk, bl, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alk, bh, acc, 0, 0, 0);
+                        }
+                        float t = 0.0f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 wq = L.w1[j][q][lane];
+                            t = fmaf(wq.x, acc[4 * q + 0], t);
+                            t = fmaf(wq.y, acc[4 * q + 1], t);
+                            t = fmaf(wq.z, acc[4 * q + 2], t);
+                            t = fmaf(wq.w, acc[4 * q + 3], t);
+                        }
+                        // axis-0 weight of plane z for my point (zero outside its window), times the tile's scale
+                        const int l0 = z - (L.c0[j][r32] - m);
+                        const float d0 = L.f0[j][r32] + (float)(m - l0);
+                        float p0 = __builtin_amdgcn_exp2f(sc * d0 * d0) * pinv;
+                        p0 = (unsigned)l0 < (unsigned)W ? p0 : 0.0f;
+                        yacc[j] = fmaf(p0, t, yacc[j]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) raw[e] = nxt[e];
+            }
+        }
+        __syncthreads();  // every wave is done with the fragments: the area becomes the result stage
+#pragma unroll
+        for (int j = 0; j < kIcBlocks; ++j) {
+            float y = yacc[j];
+            y += __shfl_xor(y, 32);  // the two row halves of the point
+            if (j < nblk && h == 0) ystage[(j * 32 + r32) * kIcStageStride + wave] = y * norm;
+        }
+        __syncthreads();
+        // thread -> (point of the group, column): the columns of a point are contiguous in y
+        for (int e = tid; e < npts * kIcWaves; e += kIcThreads) {
+            const int p = e / kIcWaves, w = e - p * kIcWaves;
+            const int c = cr0 + w;
+            const int64_t pl = (int64_t)b * Cr + c;
+            if (c < Cr && pl >= plane0 && pl < plane0 + nplanes)
+                yr[(int64_t)perm[c_begin + p] * Cr + c] = ystage[p * kIcStageStride + w];
+        }
+    }
+    }  // work items
+}
+
+} // namespace
+
+// Worth it from 4 real columns up (half the waves busy); 3-D wide tiling only.
+bool interp_cols_supported(const Geom &g, int64_t Cr)
+{
+    static const bool off = [] {
+        const char *env = std::getenv("NFFT_HIP_GATHER");
+        return env && (env[0] == 'l' || env[0] == 'm');  // lds: lane-per-point kernel, mfma: plane-ring kernel
+    }();
+    return !off && g.dim == 3 && g.wide && !g.owned && Cr >= 4;
+}
+
+template <int W>
+static int launch_ic_t(const Geom &g, const PlanLayout &L, const void *plan, const float *grid, int64_t n, int64_t Cr,
+                       int64_t plane0, int64_t nplanes, float *yr, hipStream_t stream)
+{
+    const char *base = (const char *)plan;
+    const int *to = (const int *)(base + L.off_offsets);
+    const int *perm = (const int *)(base + L.off_perm);
+    const float *spos = (const float *)(base + L.off_spos);
+    const int *first_end = (const int *)(base + L.off_cursor);
+    const int64_t pencils = (int64_t)g.nta[1] * g.nta[2];
+    int64_t nsets = g.tiles_per_batch > 0 ? L.ntiles / g.tiles_per_batch : 1;
+    if (nsets < 1) nsets = 1;
+    const int nsegm = seg_base_runs(n, nsets, pencils, g.M, device_cu_count());
+    const int seg_slabs = (g.M + nsegm - 1) / nsegm;
+    // column groups that intersect the planes [plane0, plane0 + nplanes)
+    const int64_t G = (Cr + kIcWaves - 1) / kIcWaves;
+    auto group_of = [&](int64_t pl) { return (pl / Cr) * G + (pl % Cr) / kIcWaves; };
+    const int64_t group0 = group_of(plane0), ngroups = group_of(plane0 + nplanes - 1) - group0 + 1;
+    if (ngroups > 65535) { set_error("Input mismatch: too many planes for one interpolate call"); return 1; }
+    static DeviceOnce attr_done;
+    if (attr_done.first_use()) {
+        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)interp_cols_kernel<W, false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(IcLds)));
+        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)interp_cols_kernel<W, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(IcLds)));
+        attr_done.mark();
+    }
+    const dim3 blocks((unsigned)(pencils * nsegm), (unsigned)ngroups);
+    hipLaunchKernelGGL((interp_cols_kernel<W, false>), blocks, dim3(kIcThreads), sizeof(IcLds), stream, g, to, perm, spos,
+                       grid, (int)Cr, plane0, nplanes, group0, yr, seg_slabs, nsegm, first_end, (const int4 *)nullptr);
+    if (L.two_level) {
+        const int4 *overflow = (const int4 *)(base + L.off_tmp);
+        const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)ngroups);
+        hipLaunchKernelGGL((interp_cols_kernel<W, true>), oblocks, dim3(kIcThreads), sizeof(IcLds), stream, g, to, perm,
+                           spos, grid, (int)Cr, plane0, nplanes, group0, yr, seg_slabs, nsegm, first_end, overflow);
+    }
+    NFFT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_interp_cols(const Geom &g, const PlanLayout &L, const void *plan, const float *grid, int64_t n, int64_t Cr,
+                       int64_t plane0, int64_t nplanes, float *yr, hipStream_t stream)
+{
+    if (nplanes <= 0 || n <= 0) return 0;
+    switch (g.m) {
+    case 1: return launch_ic_t<4>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 2: return launch_ic_t<6>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 3: return launch_ic_t<8>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 4: return launch_ic_t<10>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 5: return launch_ic_t<12>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 6: return launch_ic_t<14>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 7: return launch_ic_t<16>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
+    }
+    set_error("matrix-core interpolation supports cutoff 1..7");
+    return 1;
+}
+
+} // namespace nfft

@@ -34,6 +34,11 @@ bool interp_mfma_supported(const Geom &g);
 int launch_interp_mfma(const Geom &g, const PlanLayout &L, const void *plan, const float *grid, int64_t n, int64_t Cr,
                        int64_t plane0, int64_t nplanes, float *yr, hipStream_t stream);
 
+// several coefficient columns per workgroup, one wave per column (interp_cols.hip): the point-side operands are built
+// once for 8 columns, each wave streams its own column's planes from global memory
+bool interp_cols_supported(const Geom &g, int64_t Cr);
+int launch_interp_cols(const Geom &g, const PlanLayout &L, const void *plan, const float *grid, int64_t n, int64_t Cr,
+                       int64_t plane0, int64_t nplanes, float *yr, hipStream_t stream);
 
 // spectral.hip
 // adjoint roll-off: spec = R2C(grid) per real plane [nplanes, M^(d-1) * (M/2+1)] complex -> y [B, N^d, C]

@@ -207,14 +207,21 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
         if constexpr (OWNED) {
             // every owned plane is written exactly once, whether or not points reached it
             if (owner && myz >= sb && myz < se) {  // (the builder waves own nothing)
+                // the owned variant accumulates the TRANSPOSED tile (operands swapped in the MFMA): lane = grid row,
+                // registers 4q .. 4q+3 = four consecutive grid columns -> eight 16-byte stores per lane and plane
+                // instead of 32 4-byte ones (the flush is bound by store instructions, not by bytes)
                 const float zscale = ((myz + m) & 1) ? -unscale : unscale;
+                float *const grow = gplane + ((int64_t)myz * g.M + tb1 + r32) * g.M + tb2 + 4 * h;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    float *const gcol = gplane + ((int64_t)myz * g.M + tb1) * g.M + tb2 + 32 * t + r32;
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                        gcol[(int64_t)row * g.M] = (t == 0 ? acc0[reg] : acc1[reg]) * zscale;
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+                        v.x = (t == 0 ? acc0[4 * q + 0] : acc1[4 * q + 0]) * zscale;
+                        v.y = (t == 0 ? acc0[4 * q + 1] : acc1[4 * q + 1]) * zscale;
+                        v.z = (t == 0 ? acc0[4 * q + 2] : acc1[4 * q + 2]) * zscale;
+                        v.w = (t == 0 ? acc0[4 * q + 3] : acc1[4 * q + 3]) * zscale;
+                        *(f32x4 *)(grow + 32 * t + 8 * q) = v;
                     }
                 }
             }
@@ -440,12 +447,22 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                 const f16x8 ah = __builtin_bit_cast(f16x8, uh), al = __builtin_bit_cast(f16x8, ul);
                 const f16x8 b0h = O.bfrag[j][0][0][lane], b0l = O.bfrag[j][0][1][lane];
                 const f16x8 b1h = O.bfrag[j][1][0][lane], b1l = O.bfrag[j][1][1][lane];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0h, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1h, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0l, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1l, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b0h, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1h, acc1, 0, 0, 0);
+                if constexpr (OWNED) {
+                    // transposed product (columns x rows): the fragments of the two operands have the same lane layout
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0h, ah, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1h, ah, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0l, ah, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1l, ah, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0h, al, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1h, al, acc1, 0, 0, 0);
+                } else {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0h, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1h, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0l, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1l, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b0h, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1h, acc1, 0, 0, 0);
+                }
                 dirty = true;
             }
         }
