@@ -33,18 +33,25 @@ namespace {
 
 constexpr int kIcWaves = 8;                 // columns per workgroup
 constexpr int kIcThreads = kIcWaves * 64;
-constexpr int kIcBlocks = 12;               // blocks of 32 points resident at a time
+constexpr int kIcBlocks = 10;               // blocks of 32 points resident at a time
 
+// Everything a block of 32 points shares between the columns, contiguous (13 KB): the sweep addresses it as
+// (block base) + lane * 16 + instruction offset, one address register for all of it.
+struct __align__(16) IcBlock {
+    f16x8 bfrag[4][2][64];                  // [k-step][hi/lo][lane = 32 (column half) + point]
+    f32x4 w1[5][64];                        // [quad][lane]: psi1 of the lane's point on its 16 rows (quads 0-3); quad 4 =
+                                            // {fraction along axis 0, cell along axis 0 (int bits; far outside every
+                                            // window for padding lanes), -, -}
+};
 struct __align__(16) IcLds {
-    f16x8 bfrag[kIcBlocks][4][2][64];       // [block][k-step][hi/lo][lane = 32 (column half) + point]   96 KB
-    f32x4 w1[kIcBlocks][4][64];             // [block][register quad][lane]: psi1 of the lane's point on its 16 rows  48 KB
-    float f0[kIcBlocks][32];                // fraction along axis 0
-    int c0[kIcBlocks][32];                  // cell along axis 0 (unwrapped slab), INT_MIN/2 for padding lanes
+    IcBlock blk[kIcBlocks];                 // 130 KB
+    float yacc[kIcWaves][kIcBlocks][64];    // running sums of a wave's column, per block and lane   20 KB
     int zf[kIcBlocks], zl[kIcBlocks];       // first / last plane of the block's window
 };
-// after a group's sweep the fragment area is reused to transpose the results: [point of the group][column]
+// after a group's sweep the block area is reused to transpose the results: [point of the group][column]
 constexpr int kIcStageStride = kIcWaves + 1;
-static_assert(kIcBlocks * 32 * kIcStageStride * 4 <= (int)sizeof(f16x8) * kIcBlocks * 4 * 2 * 64, "stage fits");
+static_assert(kIcBlocks * 32 * kIcStageStride * 4 <= (int)sizeof(IcBlock) * kIcBlocks, "stage fits");
+static_assert(sizeof(IcLds) <= 160 * 1024, "LDS budget");
 
 template <int W, bool OVERFLOW>
 __global__ void __launch_bounds__(kIcThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -56,7 +63,7 @@ interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
     constexpr int m = W / 2 - 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     IcLds &L = *reinterpret_cast<IcLds *>(smem_raw);
-    float *const ystage = reinterpret_cast<float *>(&L.bfrag[0][0][0][0]);
+    float *const ystage = reinterpret_cast<float *>(&L.blk[0]);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -103,29 +110,31 @@ interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
     // row of this lane inside the plane and its eight 8-column pieces (two 16-byte loads each)
     const int64_t grow_off = (int64_t)wrap_near(tb1 - m + r32, M) * M;
     const int ccol0 = tb2 - m + 8 * h;  // + 16 ks
-    const bool fast_cols = tb2 - m >= 0 && tb2 - m + 64 <= M;  // no periodic wrap inside the padded columns
+    // Periodic wrap of the padded columns (edge pencils only): 4-float pieces are wrapped as a whole; if the boundary
+    // would cut through a piece (start column not a multiple of 4) the tile is read float by float.
+    const bool wraps = tb2 - m < 0 || tb2 - m + 64 > M;
+    const bool straddle = wraps && ((tb2 - m) & 3) != 0;  // workgroup-uniform
+    const int cbase = ccol0 < 0 ? ccol0 + M : ccol0;      // first column of this lane's pieces, in [0, M)
 
     auto load_tile = [&](const int z, f32x4 (&raw)[8]) {
         const float *const prow = gplane + (int64_t)wrap(z, M) * M * M + grow_off;
-        if (fast_cols) {
+        if (!straddle) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                raw[2 * ks] = *(const f32x4 *)(prow + ccol0 + 16 * ks);
-                raw[2 * ks + 1] = *(const f32x4 *)(prow + ccol0 + 16 * ks + 4);
+            for (int e = 0; e < 8; ++e) {
+                const int k = 16 * (e >> 1) + 4 * (e & 1);
+                const int c = cbase + k;
+                raw[e] = *(const f32x4 *)(prow + (c >= M ? c - M : c));
             }
         } else {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int c = ccol0 + 16 * ks + 4 * e;
-                    f32x4 v;
-                    v.x = prow[wrap_near(c, M)];
-                    v.y = prow[wrap_near(c + 1, M)];
-                    v.z = prow[wrap_near(c + 2, M)];
-                    v.w = prow[wrap_near(c + 3, M)];
-                    raw[2 * ks + e] = v;
-                }
+            for (int e = 0; e < 8; ++e) {
+                const int c = cbase + 16 * (e >> 1) + 4 * (e & 1);
+                f32x4 v;
+                v.x = prow[c >= M ? c - M : c];
+                v.y = prow[c + 1 >= M ? c + 1 - M : c + 1];
+                v.z = prow[c + 2 >= M ? c + 2 - M : c + 2];
+                v.w = prow[c + 3 >= M ? c + 3 - M : c + 3];
+                raw[e] = v;
             }
         }
     };
@@ -150,10 +159,8 @@ interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
             const int zf = __builtin_amdgcn_readlane(c0, 0) - m;
             const int zl = __builtin_amdgcn_readlane(c0, nvalid - 1) + m + 1;
             if (lane == 0) { L.zf[j] = zf; L.zl[j] = zl; }
-            if (h == 0) {
-                L.f0[j][r32] = f0;
-                L.c0[j][r32] = valid ? c0 : -(1 << 28);  // padding lanes: outside every window
-            }
+            IcBlock &Bk = L.blk[j];
+            Bk.w1[4][lane] = f32x4{f0, __int_as_float(valid ? c0 : -(1 << 28)), 0.0f, 0.0f};  // padding: outside every window
             // B fragments: psi2 of my point on the padded columns 16 ks + 8 h + jj (zero outside the window)
             const int o2 = c2 - tb2;  // padded column of tap 0
 #pragma unroll
@@ -171,8 +178,8 @@ interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
                 split_pair(w[2], w[3], h1, q1);
                 split_pair(w[4], w[5], h2, q2);
                 split_pair(w[6], w[7], h3, q3);
-                L.bfrag[j][ks][0][lane] = __builtin_bit_cast(f16x8, u32x4{h0, h1, h2, h3});
-                L.bfrag[j][ks][1][lane] = __builtin_bit_cast(f16x8, u32x4{q0, q1, q2, q3});
+                Bk.bfrag[ks][0][lane] = __builtin_bit_cast(f16x8, u32x4{h0, h1, h2, h3});
+                Bk.bfrag[ks][1][lane] = __builtin_bit_cast(f16x8, u32x4{q0, q1, q2, q3});
             }
             // psi1 of my point on the 16 rows this lane holds of every T_z (MFMA result layout)
             const int o1 = c1 - tb1;
@@ -187,24 +194,24 @@ interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
                     const float ev = __builtin_amdgcn_exp2f(sc * d * d);
                     wv[r] = (valid && (unsigned)l1 < (unsigned)W) ? ev : 0.0f;
                 }
-                L.w1[j][q][lane] = f32x4{wv[0], wv[1], wv[2], wv[3]};
+                Bk.w1[q][lane] = f32x4{wv[0], wv[1], wv[2], wv[3]};
             }
         }
         __syncthreads();
 
         // ---- plane sweep of this wave's column -------------------------------------------------------------------
-        float yacc[kIcBlocks];
-#pragma unroll
-        for (int j = 0; j < kIcBlocks; ++j) yacc[j] = 0.0f;
+        for (int j = 0; j < nblk; ++j) L.yacc[wave][j][lane] = 0.0f;  // (read and written by this lane only)
         if (col_active) {
             const int z_first = L.zf[0], z_last = L.zl[nblk - 1];
-            // windows of the blocks, wave-uniform: lane j holds block j's
+            // windows of the blocks, wave-uniform: lane j holds block j's.  They are sorted (the points are sorted by
+            // slab), so the blocks whose window holds plane z are a range [jlo, jhi) that only moves forward.
             const int zf_l = lane < nblk ? L.zf[lane] : (1 << 28);
-            const int zl_l = lane < nblk ? L.zl[lane] : -(1 << 28);
-            f32x4 raw[8], nxt[8];
-            load_tile(z_first, raw);
-            for (int z = z_first; z <= z_last; ++z) {
-                if (z < z_last) load_tile(z + 1, nxt);
+            const int zl_l = lane < nblk ? L.zl[lane] : (1 << 28);
+            int jlo = 0, jhi = 0;
+            // one plane of the sweep: `raw` holds its tile (requested a whole plane step earlier)
+            auto do_plane = [&](const int z, f32x4 (&raw)[8]) {
+                while (jhi < nblk && __builtin_amdgcn_readlane(zf_l, jhi) <= z) ++jhi;
+                while (jlo < jhi && __builtin_amdgcn_readlane(zl_l, jlo) < z) ++jlo;
                 // power-of-two scale: max |G| of the tile lands in [1024, 2048); odd planes enter negated (the MFMA
                 // accumulation truncates with a small sign-independent bias that cancels over alternating planes)
                 float mx = 0.0f;
@@ -212,7 +219,7 @@ interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
                 for (int e = 0; e < 8; ++e)
                     mx = fmaxf(fmaxf(fmaxf(mx, fabsf(raw[e].x)), fabsf(raw[e].y)), fmaxf(fabsf(raw[e].z), fabsf(raw[e].w)));
                 for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-                if (mx > 0.0f) {  // (an all-zero tile adds nothing)
+                if (mx > 0.0f && jlo < jhi) {  // (an all-zero tile adds nothing)
                     float scale = 1.0f, pinv = 1.0f / kOpScale;
                     if (mx > 1.0e-30f && mx < 3.0e38f) {
                         int ex;
@@ -233,14 +240,12 @@ interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
                         ah[ks] = u32x4{h0, h1, h2, h3};
                         al[ks] = u32x4{q0, q1, q2, q3};
                     }
-#pragma unroll
-                    for (int j = 0; j < kIcBlocks; ++j) {
-                        const int zf = __builtin_amdgcn_readlane(zf_l, j), zl = __builtin_amdgcn_readlane(zl_l, j);
-                        if (z < zf || z > zl) continue;  // wave-uniform
+                    for (int j = jlo; j < jhi; ++j) {
+                        const IcBlock &Bk = L.blk[j];
                         f32x16 acc = 0.0f;
 #pragma unroll
                         for (int ks = 0; ks < 4; ++ks) {
-                            const f16x8 bh = L.bfrag[j][ks][0][lane], bl = L.bfrag[j][ks][1][lane];
+                            const f16x8 bh = Bk.bfrag[ks][0][lane], bl = Bk.bfrag[ks][1][lane];
                             const f16x8 ahk = __builtin_bit_cast(f16x8, ah[ks]), alk = __builtin_bit_cast(f16x8, al[ks]);
                             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahk, bh, acc, 0, 0, 0);
                             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahk, bl, acc, 0, 0, 0);
@@ -249,28 +254,40 @@ interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
                         float t = 0.0f;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const f32x4 wq = L.w1[j][q][lane];
+                            const f32x4 wq = Bk.w1[q][lane];
                             t = fmaf(wq.x, acc[4 * q + 0], t);
                             t = fmaf(wq.y, acc[4 * q + 1], t);
                             t = fmaf(wq.z, acc[4 * q + 2], t);
                             t = fmaf(wq.w, acc[4 * q + 3], t);
                         }
                         // axis-0 weight of plane z for my point (zero outside its window), times the tile's scale
-                        const int l0 = z - (L.c0[j][r32] - m);
-                        const float d0 = L.f0[j][r32] + (float)(m - l0);
+                        const f32x4 aux = Bk.w1[4][lane];
+                        const int l0 = z - (__float_as_int(aux.y) - m);
+                        const float d0 = aux.x + (float)(m - l0);
                         float p0 = __builtin_amdgcn_exp2f(sc * d0 * d0) * pinv;
                         p0 = (unsigned)l0 < (unsigned)W ? p0 : 0.0f;
-                        yacc[j] = fmaf(p0, t, yacc[j]);
+                        L.yacc[wave][j][lane] = fmaf(p0, t, L.yacc[wave][j][lane]);
                     }
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) raw[e] = nxt[e];
+                // the registers of this tile take the tile two planes ahead (the next plane's is already in flight)
+                if (z + 2 <= z_last) load_tile(z + 2, raw);
+            };
+            f32x4 ta[8], tb[8];
+            load_tile(z_first, ta);
+            if (z_first + 1 <= z_last) load_tile(z_first + 1, tb);
+            for (int z = z_first; z <= z_last; z += 2) {
+                do_plane(z, ta);
+                if (z + 1 <= z_last) do_plane(z + 1, tb);
             }
         }
-        __syncthreads();  // every wave is done with the fragments: the area becomes the result stage
+        // this lane's sums out of the LDS before the block area becomes the result stage
+        float ysum[kIcBlocks];
+#pragma unroll
+        for (int j = 0; j < kIcBlocks; ++j) ysum[j] = j < nblk ? L.yacc[wave][j][lane] : 0.0f;
+        __syncthreads();  // every wave is done with the fragments
 #pragma unroll
         for (int j = 0; j < kIcBlocks; ++j) {
-            float y = yacc[j];
+            float y = ysum[j];
             y += __shfl_xor(y, 32);  // the two row halves of the point
             if (j < nblk && h == 0) ystage[(j * 32 + r32) * kIcStageStride + wave] = y * norm;
         }
