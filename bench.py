@@ -136,10 +136,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # (NFFT_BENCH_FORCE_DIST=1 under a 1-rank launcher runs the multi-rank code path on one GPU: a rehearsal)
+    distributed = world > 1 or os.environ.get("NFFT_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    json_out = sys.stdout
     if distributed:
+        # RCCL prints a version banner on the C-level stdout when its first communicator comes up: send everything
+        # that is not the result line to stderr, so that rank 0's stdout carries exactly ONE line, the JSON
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
     n_gpus = world
@@ -394,7 +401,8 @@ def main():
         }
         if not args.no_cpu_baseline and not distributed:
             out["cpu_baseline"] = cpu_baseline(d, N, args.cpu_seconds)
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
