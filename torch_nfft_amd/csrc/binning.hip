@@ -17,6 +17,8 @@ constexpr int kSortBlockPoints = 16384; // points per workgroup in the first-lev
                                         // scatter writes 16-byte records, ~18 per (workgroup, bin) at C3)
 constexpr int kSortThreads = 512;
 constexpr int kMaxPencilsLds = 8192;    // first-level bins that fit an LDS histogram
+constexpr int kSort2Parts = 8;          // workgroups that share one first-level bin in the second level (a dense bin of a
+                                        // clustered input is otherwise one workgroup's serial loop: 1.4 ms at C3-clustered)
 
 PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)
 {
@@ -39,6 +41,8 @@ PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)
     L.off_hist = o;    o = align_up(o + (L.two_level ? scan_items * 4 : 0), 256);
     L.off_hscan = o;   o = align_up(o + (L.two_level ? scan_items * 4 : 0), 256);
     L.off_tmp = o;     o = align_up(o + (L.two_level ? L.cap * 16 : 0), 256);
+    // second level: per (first-level bin, part) counts of the fine keys
+    L.off_hist2 = o;   o = align_up(o + (L.two_level ? L.npencils * kSort2Parts * (int64_t)g.l1bins * g.SB * 4 : 0), 256);
     L.total = o;
     return L;
 }
@@ -222,69 +226,106 @@ __device__ __forceinline__ int fine_key(const Geom &g, const float4 rec, const i
     return key;
 }
 
-__global__ void __launch_bounds__(kSortThreads)
-sort2_kernel(Geom g, int64_t n, int npencils, int nblocks, const int *__restrict__ hscan,
-             const float4 *__restrict__ tmp, int *__restrict__ offsets, int *__restrict__ perm,
-             float *__restrict__ spos)
+// Second level: the records of first-level bin l1 are counting-sorted by fine key (slab, sub-block) by kSort2Parts
+// workgroups, each taking an equal share of the bin's records: a count pass (per-part histograms to HBM) and a
+// scatter pass whose prologue turns the bin's small table of counts into this part's cursors.
+__device__ __forceinline__ void sort2_range(const int *__restrict__ hscan, int l1, int nblocks, int part, int &p0,
+                                            int &r0, int &r1)
 {
-    extern __shared__ int lds2[];  // [bins of this first-level bin * SB] counts -> cursors
-    const int l1 = blockIdx.x;
-    const int pencil = l1 / g.l1seg, sg = l1 - pencil * g.l1seg;
-    const int bin_lo = sg * g.l1bins;
-    const int nt0 = (min(g.np0, bin_lo + g.l1bins) - bin_lo) * g.SB;  // (axis-0 bin, sub-block) bins handled here
-    const int64_t obase = ((int64_t)pencil * g.np0 + bin_lo) * g.SB;   // their first entry in the offsets table
-    const int p0 = hscan[(int64_t)l1 * nblocks];
     // (the scan has one item more than there are (bin, block) counts: its last entry is the number of plan entries,
     // n for ordinary plans, larger for the owned tiling)
+    p0 = hscan[(int64_t)l1 * nblocks];
     const int p1 = hscan[(int64_t)(l1 + 1) * nblocks];
+    const int64_t len = p1 - p0;
+    r0 = p0 + (int)(len * part / kSort2Parts);
+    r1 = p0 + (int)(len * (part + 1) / kSort2Parts);
+}
+
+__global__ void __launch_bounds__(kSortThreads)
+sort2_count_kernel(Geom g, int nblocks, const int *__restrict__ hscan, const float4 *__restrict__ tmp,
+                   int *__restrict__ hist2 /* [l1][part][key] */)
+{
+    extern __shared__ int lds2[];
+    const int l1 = blockIdx.x, part = blockIdx.y;
+    const int pencil = l1 / g.l1seg, sg = l1 - pencil * g.l1seg;
+    const int bin_lo = sg * g.l1bins;
+    const int nt0 = (min(g.np0, bin_lo + g.l1bins) - bin_lo) * g.SB;  // fine keys of this first-level bin
+    int p0, r0, r1;
+    sort2_range(hscan, l1, nblocks, part, p0, r0, r1);
     for (int i = threadIdx.x; i < nt0; i += kSortThreads) lds2[i] = 0;
     __syncthreads();
-    // (eight records per thread in flight: a dense bin of a clustered input is one workgroup's serial loop)
-    for (int j0 = p0 + threadIdx.x; j0 < p1; j0 += kSortThreads * 8) {
+    for (int j0 = r0 + threadIdx.x; j0 < r1; j0 += kSortThreads * 8) {
         float4 rec[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int j = j0 + q * kSortThreads;
-            rec[q] = j < p1 ? tmp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            rec[q] = j < r1 ? tmp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-            if (j0 + q * kSortThreads < p1) atomicAdd(&lds2[fine_key(g, rec[q], bin_lo)], 1);
+            if (j0 + q * kSortThreads < r1) atomicAdd(&lds2[fine_key(g, rec[q], bin_lo)], 1);
     }
     __syncthreads();
-    // exclusive scan of the nt0 chunk counts by one wave (nt0 is small: M / TC)
+    int *out = hist2 + ((int64_t)l1 * kSort2Parts + part) * g.l1bins * g.SB;
+    for (int i = threadIdx.x; i < nt0; i += kSortThreads) out[i] = lds2[i];
+}
+
+__global__ void __launch_bounds__(kSortThreads)
+sort2_scatter_kernel(Geom g, int npencils, int nblocks, const int *__restrict__ hscan, const float4 *__restrict__ tmp,
+                     const int *__restrict__ hist2, int *__restrict__ offsets, int *__restrict__ perm,
+                     float *__restrict__ spos)
+{
+    extern __shared__ int lds2[];  // [fine keys]: totals -> this part's cursors
+    const int l1 = blockIdx.x, part = blockIdx.y;
+    const int pencil = l1 / g.l1seg, sg = l1 - pencil * g.l1seg;
+    const int bin_lo = sg * g.l1bins;
+    const int nt0 = (min(g.np0, bin_lo + g.l1bins) - bin_lo) * g.SB;
+    const int64_t obase = ((int64_t)pencil * g.np0 + bin_lo) * g.SB;   // first entry of these keys in the offsets table
+    int p0, r0, r1;
+    sort2_range(hscan, l1, nblocks, part, p0, r0, r1);
+    const int *table = hist2 + (int64_t)l1 * kSort2Parts * g.l1bins * g.SB;
+    const int kstride = g.l1bins * g.SB;
+    // exclusive scan over the keys of (total over the parts) by one wave; cursor = p0 + keys before + parts before
     if (threadIdx.x < 64) {
         int carry = 0;
         for (int base = 0; base < nt0; base += 64) {
             const int idx = base + threadIdx.x;
-            const int v = idx < nt0 ? lds2[idx] : 0;
-            int incl = v;
+            int tot = 0, before = 0;
+            if (idx < nt0) {
+#pragma unroll
+                for (int q = 0; q < kSort2Parts; ++q) {
+                    const int c = table[q * kstride + idx];
+                    tot += c;
+                    before += q < part ? c : 0;
+                }
+            }
+            int incl = tot;
             for (int off = 1; off < 64; off <<= 1) {
                 const int t = __shfl_up(incl, off);
                 if ((int)threadIdx.x >= off) incl += t;
             }
             if (idx < nt0) {
-                const int excl = carry + incl - v;
-                lds2[idx] = excl;                      // cursor of chunk idx (relative to p0)
-                offsets[obase + idx] = p0 + excl;
+                const int excl = carry + incl - tot;
+                lds2[idx] = p0 + excl + before;
+                if (part == 0) offsets[obase + idx] = p0 + excl;
             }
             carry += __shfl(incl, 63);
         }
-        if (l1 == npencils - 1 && threadIdx.x == 0) offsets[obase + nt0] = p1;
+        if (part == 0 && l1 == npencils - 1 && threadIdx.x == 0) offsets[obase + nt0] = p0 + carry;  // = entries
     }
     __syncthreads();
-    for (int j0 = p0 + threadIdx.x; j0 < p1; j0 += kSortThreads * 8) {
+    for (int j0 = r0 + threadIdx.x; j0 < r1; j0 += kSortThreads * 8) {
         float4 recs[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int j = j0 + q * kSortThreads;
-            recs[q] = j < p1 ? tmp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            recs[q] = j < r1 ? tmp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            if (j0 + q * kSortThreads >= p1) continue;
+            if (j0 + q * kSortThreads >= r1) continue;
             const float4 rec = recs[q];
-            const int slot = p0 + atomicAdd(&lds2[fine_key(g, rec, bin_lo)], 1);
+            const int slot = atomicAdd(&lds2[fine_key(g, rec, bin_lo)], 1);
             perm[slot] = __float_as_int(rec.w);
             spos[(int64_t)slot * g.dim] = rec.x;
             if (g.dim > 1) spos[(int64_t)slot * g.dim + 1] = rec.y;
@@ -412,8 +453,12 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
         NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(base + L.off_scan, scan_bytes, hist, hscan, (int)items, stream));
         hipLaunchKernelGGL(sort1_scatter_kernel, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
                            npencils, nblocks, hscan, tmp);
-        hipLaunchKernelGGL(sort2_kernel, dim3(npencils), dim3(kSortThreads), (size_t)g.l1bins * g.SB * 4, stream, g, n,
-                           npencils, nblocks, hscan, tmp, offsets, perm, spos);
+        int *hist2 = (int *)(base + L.off_hist2);
+        const size_t lds2 = (size_t)g.l1bins * g.SB * 4;
+        hipLaunchKernelGGL(sort2_count_kernel, dim3(npencils, kSort2Parts), dim3(kSortThreads), lds2, stream, g, nblocks,
+                           hscan, tmp, hist2);
+        hipLaunchKernelGGL(sort2_scatter_kernel, dim3(npencils, kSort2Parts), dim3(kSortThreads), lds2, stream, g, npencils,
+                           nblocks, hscan, tmp, hist2, offsets, perm, spos);
         if (g.wide) {
             // the record area is free now: it holds the overflow list of the load-balance split
             NFFT_HIP_CHECK(hipMemsetAsync(tmp, 0, 16, stream));

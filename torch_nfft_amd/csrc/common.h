@@ -291,7 +291,7 @@ struct PlanLayout {
     int64_t npencils, nblocks;  // two-level sort geometry
     bool two_level;
     int64_t off_offsets, off_cursor, off_perm, off_spos, off_scan, scan_bytes;
-    int64_t off_hist, off_hscan, off_tmp;
+    int64_t off_hist, off_hscan, off_tmp, off_hist2;
     int64_t total;
 };
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
