@@ -31,6 +31,9 @@ struct ColGeom {
     int Mh;             // M/2 + 1
     int SR;             // row stride of the axis-2 half spectrum S: Mh (rocFFT rows) or KC (own pruned row passes)
     int KC;             // kept k2 columns: 0..H
+    int KS;             // row stride of T and of the compact S: KC rounded up to whole tiles of NC columns, so that the
+                        // NC * 8-byte runs the passes read and write start on their own 64 / 128-byte lines (rows of
+                        // 129 complex numbers put every run across two lines: the passes fetched ~2x their input)
     int NB;             // band+ rows: N + 1
     int NC, logNC;      // columns per tile
     float param;        // pi/3 * m / N^2  (phi_hat_inv exponent scale)
@@ -224,13 +227,13 @@ adj_axis1_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__rest
                      },
                      [&](int idx, float2 v) { buf[idx] = v; });
     lds_fft<false>(buf, ltw, cg, tid);
-    float2 *dst = T + ((plane * cg.M + u0) * cg.NB) * cg.KC;
+    float2 *dst = T + ((plane * cg.M + u0) * cg.NB) * cg.KS;
     for (int idx = tid; idx < (cg.NB << cg.logNC); idx += kFftThreads) {
         const int col = idx & (cg.NC - 1), j1 = idx >> cg.logNC;
         const int k2 = c0 + col;
         if (k2 < cg.KC) {
             const int k1 = (j1 - cg.H) & (cg.M - 1);
-            dst[(int64_t)j1 * cg.KC + k2] = buf[(brev_row(k1, cg.logM) << cg.logNC) + col];
+            dst[(int64_t)j1 * cg.KS + k2] = buf[(brev_row(k1, cg.logM) << cg.logNC) + col];
         }
     }
 }
@@ -268,8 +271,8 @@ adj_axis0_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__rest
     const int64_t col_local = blockIdx.z;  // (batch, column) pair inside this chunk of planes
     stage_twiddles(ltw, tw, cg.M, tid);
     const int64_t plane = XCOMPLEX ? col_local * 2 : col_local;
-    const int64_t pstride = (int64_t)cg.M * cg.NB * cg.KC;
-    const float2 *src = T + plane * pstride + (int64_t)j1 * cg.KC;
+    const int64_t pstride = (int64_t)cg.M * cg.NB * cg.KS;
+    const float2 *src = T + plane * pstride + (int64_t)j1 * cg.KS;
     for (int part = 0; part < (XCOMPLEX ? 2 : 1); ++part) {
         float2 *const dstbuf = part ? buf2 : buf;
         const float2 *const srcp = src + part * pstride;
@@ -277,7 +280,7 @@ adj_axis0_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__rest
                          [&](int idx) {
                              const int col = idx & (cg.NC - 1), u0 = idx >> cg.logNC;
                              const int k2 = c0 + col;
-                             return k2 < cg.KC ? srcp[(int64_t)u0 * cg.NB * cg.KC + k2] : make_float2(0.f, 0.f);
+                             return k2 < cg.KC ? srcp[(int64_t)u0 * cg.NB * cg.KS + k2] : make_float2(0.f, 0.f);
                          },
                          [&](int idx, float2 v) { dstbuf[idx] = v; });
     }
@@ -372,11 +375,11 @@ fwd_axis0_kernel(ColGeom cg, const float2 *__restrict__ tw, const void *__restri
                         if (c0 + col < cg.KC) buf[(((j0 - H) & (cg.M - 1)) << cg.logNC) + col] = v;
                     });
     lds_fft<true>(buf, ltw, cg, tid);
-    float2 *dst = T + pl * ((int64_t)cg.M * cg.NB * cg.KC) + (int64_t)j1 * cg.KC;
+    float2 *dst = T + pl * ((int64_t)cg.M * cg.NB * cg.KS) + (int64_t)j1 * cg.KS;
     for (int idx = tid; idx < (cg.M << cg.logNC); idx += kFftThreads) {
         const int col = idx & (cg.NC - 1), u0 = idx >> cg.logNC;
         const int k2 = c0 + col;
-        if (k2 < cg.KC) dst[(int64_t)u0 * cg.NB * cg.KC + k2] = buf[(brev_row(u0, cg.logM) << cg.logNC) + col];
+        if (k2 < cg.KC) dst[(int64_t)u0 * cg.NB * cg.KS + k2] = buf[(brev_row(u0, cg.logM) << cg.logNC) + col];
     }
 }
 
@@ -392,7 +395,7 @@ fwd_axis1_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__rest
     const int u0 = blockIdx.y;
     const int64_t plane = blockIdx.z;
     float2 *dst = S + ((plane * cg.M + u0) * cg.M) * cg.SR;
-    const int width = cg.SR == cg.KC ? cg.KC : cg.Mh;  // columns of S that exist (the compact layout has no zero tail)
+    const int width = cg.SR == cg.KS ? cg.KC : cg.Mh;  // columns of S that exist (the compact layout has no zero tail)
     if (c0 >= cg.KC) {  // zero tail of the padded half spectrum
         for (int idx = tid; idx < (cg.M << cg.logNC); idx += kFftThreads) {
             const int col = idx & (cg.NC - 1), u1 = idx >> cg.logNC;
@@ -403,12 +406,12 @@ fwd_axis1_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__rest
     stage_twiddles(ltw, tw, cg.M, tid);
     for (int idx = tid; idx < (cg.M << cg.logNC); idx += kFftThreads) buf[idx] = make_float2(0.f, 0.f);
     __syncthreads();
-    const float2 *src = T + ((plane * cg.M + u0) * cg.NB) * cg.KC;
+    const float2 *src = T + ((plane * cg.M + u0) * cg.NB) * cg.KS;
     batched_fill<16>(cg.NB << cg.logNC, tid,
                      [&](int idx) {
                          const int col = idx & (cg.NC - 1), j1 = idx >> cg.logNC;
                          const int k2 = c0 + col;
-                         return k2 < cg.KC ? src[(int64_t)j1 * cg.KC + k2] : make_float2(0.f, 0.f);
+                         return k2 < cg.KC ? src[(int64_t)j1 * cg.KS + k2] : make_float2(0.f, 0.f);
                      },
                      [&](int idx, float2 v) {
                          const int col = idx & (cg.NC - 1), j1 = idx >> cg.logNC;
@@ -522,10 +525,10 @@ __device__ __forceinline__ void row_tables(RowLds<LOGL> &S, const float2 *__rest
     __syncthreads();
 }
 
-// grid rows [nrows][M] real  ->  S[nrows][KC] complex
+// grid rows [nrows][M] real  ->  S[nrows][KS] complex (KC of them kept)
 template <int LOGL>
 __global__ void __launch_bounds__(kRowWaves * 64)
-row_r2c_kernel(int KC, int64_t nrows, const float2 *__restrict__ tw, const float *__restrict__ grid, float2 *__restrict__ out)
+row_r2c_kernel(int KC, int KS, int64_t nrows, const float2 *__restrict__ tw, const float *__restrict__ grid, float2 *__restrict__ out)
 {
     constexpr int L = 1 << LOGL, M = 2 * L, RP = kWaveCplx / L;
     __shared__ RowLds<LOGL> S;
@@ -546,7 +549,7 @@ row_r2c_kernel(int KC, int64_t nrows, const float2 *__restrict__ tw, const float
         }
         wave_fft<false, LOGL>(z, S.tw, lane);
         for (int rr = 0; rr < nr; ++rr) {
-            float2 *dst = out + (row + rr) * KC;
+            float2 *dst = out + (row + rr) * KS;
             for (int k = lane; k < KC; k += 64) {
                 const float2 a = z[zsw(rr * L + S.rev[k])];
                 float2 b = z[zsw(rr * L + S.rev[(L - k) & (L - 1)])];
@@ -560,10 +563,10 @@ row_r2c_kernel(int KC, int64_t nrows, const float2 *__restrict__ tw, const float
     }
 }
 
-// S[nrows][KC] complex (zero beyond the band)  ->  grid rows [nrows][M] real
+// S[nrows][KS] complex (KC of them kept, zero beyond the band)  ->  grid rows [nrows][M] real
 template <int LOGL>
 __global__ void __launch_bounds__(kRowWaves * 64)
-row_c2r_kernel(int KC, int64_t nrows, const float2 *__restrict__ tw, const float2 *__restrict__ in, float *__restrict__ grid)
+row_c2r_kernel(int KC, int KS, int64_t nrows, const float2 *__restrict__ tw, const float2 *__restrict__ in, float *__restrict__ grid)
 {
     constexpr int L = 1 << LOGL, M = 2 * L, RP = kWaveCplx / L;
     __shared__ RowLds<LOGL> S;
@@ -576,15 +579,15 @@ row_c2r_kernel(int KC, int64_t nrows, const float2 *__restrict__ tw, const float
         const int64_t row = row0 + (int64_t)r * RP;
         if (row >= nrows) break;
         const int nr = (int)min((int64_t)RP, nrows - row);
-        const float2 *src = in + row * KC;
+        const float2 *src = in + row * KS;
 #pragma unroll 4
         for (int n0 = 0; n0 < kWaveCplx; n0 += 64) {
             // Z[k] = (X[k] + conj X[L-k]) + i conj(W_M^k) (X[k] - conj X[L-k]),  X = 0 beyond the band
             const int n = n0 + lane;
             const int rr = n >> LOGL, k = n & (L - 1);
             const bool live = rr < nr;
-            const float2 a = (live && k < KC) ? src[rr * KC + k] : make_float2(0.f, 0.f);
-            float2 b = (live && (L - k) < KC) ? src[rr * KC + L - k] : make_float2(0.f, 0.f);
+            const float2 a = (live && k < KC) ? src[rr * KS + k] : make_float2(0.f, 0.f);
+            float2 b = (live && (L - k) < KC) ? src[rr * KS + L - k] : make_float2(0.f, 0.f);
             b.y = -b.y;
             const float2 sum = make_float2(a.x + b.x, a.y + b.y), dif = make_float2(a.x - b.x, a.y - b.y);
             float2 w = S.tw[k];
@@ -648,6 +651,19 @@ column_layout_kernel(const T *__restrict__ src, T *__restrict__ dst, int64_t K /
     }
 }
 
+// row stride (complex numbers) of the compact half spectrum and of T: the N/2+1 kept columns rounded up to the widest
+// tile any pass of that grid size uses
+int compact_stride(const Geom &g)
+{
+    static const int forced = [] {
+        const char *env = std::getenv("NFFT_HIP_KS_ALIGN");
+        const int v = env ? std::atoi(env) : 0;
+        return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 0;
+    }();
+    const int a = forced ? forced : (g.M >= 512 ? 8 : 16);
+    return (g.N / 2 + 1 + a - 1) / a * a;
+}
+
 ColGeom make_col_geom(const Geom &g, bool two_buffers, bool compact)
 {
     ColGeom cg;
@@ -658,7 +674,8 @@ ColGeom make_col_geom(const Geom &g, bool two_buffers, bool compact)
     cg.H = g.N / 2;
     cg.Mh = g.M / 2 + 1;
     cg.KC = cg.H + 1;
-    cg.SR = compact ? cg.KC : cg.Mh;
+    cg.KS = compact_stride(g);
+    cg.SR = compact ? cg.KS : cg.Mh;
     cg.NB = g.N + 1;
     // tile of NC columns: M * NC * 8 bytes per buffer.  32 KB tiles (NC = 8 at M = 512) let four workgroups share a
     // CU and overlap their load / transform / store phases: 6 % faster than 64 KB tiles, 16 KB tiles (64-byte row
@@ -699,12 +716,12 @@ bool colfft_supported(const Geom &g)
 int64_t colfft_scratch_bytes(const Geom &g, int64_t nplanes)
 {
     // T[plane][M][N+1][N/2+1] complex + twiddle table
-    return align_up(nplanes * (int64_t)g.M * (g.N + 1) * (g.N / 2 + 1) * 8, 256) + align_up((int64_t)g.M * 4, 256);
+    return align_up(nplanes * (int64_t)g.M * (g.N + 1) * compact_stride(g) * 8, 256) + align_up((int64_t)g.M * 4, 256);
 }
 
 static float2 *twiddle_ptr(const Geom &g, int64_t nplanes, void *scratch)
 {
-    return (float2 *)((char *)scratch + align_up(nplanes * (int64_t)g.M * (g.N + 1) * (g.N / 2 + 1) * 8, 256));
+    return (float2 *)((char *)scratch + align_up(nplanes * (int64_t)g.M * (g.N + 1) * compact_stride(g) * 8, 256));
 }
 
 int launch_colfft_adjoint(const Geom &g, const float2 *spec, bool compact, void *scratch, int64_t scratch_planes,
@@ -784,10 +801,10 @@ static void launch_rows_t(bool c2r, const Geom &g, int64_t nrows, const float2 *
     const int64_t per_wg = (int64_t)kRowWaves * kRowRounds * (kWaveCplx >> LOGL);
     const dim3 blocks((unsigned)((nrows + per_wg - 1) / per_wg));
     if (c2r)
-        hipLaunchKernelGGL((row_c2r_kernel<LOGL>), blocks, dim3(kRowWaves * 64), 0, stream, g.N / 2 + 1, nrows, tw,
+        hipLaunchKernelGGL((row_c2r_kernel<LOGL>), blocks, dim3(kRowWaves * 64), 0, stream, g.N / 2 + 1, compact_stride(g), nrows, tw,
                            (const float2 *)in, (float *)out);
     else
-        hipLaunchKernelGGL((row_r2c_kernel<LOGL>), blocks, dim3(kRowWaves * 64), 0, stream, g.N / 2 + 1, nrows, tw,
+        hipLaunchKernelGGL((row_r2c_kernel<LOGL>), blocks, dim3(kRowWaves * 64), 0, stream, g.N / 2 + 1, compact_stride(g), nrows, tw,
                            (const float *)in, (float2 *)out);
 }
 
