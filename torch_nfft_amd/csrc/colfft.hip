@@ -651,8 +651,8 @@ column_layout_kernel(const T *__restrict__ src, T *__restrict__ dst, int64_t K /
     }
 }
 
-// row stride (complex numbers) of the compact half spectrum and of T: the N/2+1 kept columns rounded up to the widest
-// tile any pass of that grid size uses
+// row stride (complex numbers) of the compact half spectrum and of T: the N/2+1 kept columns rounded up so that the
+// runs of a tile start on 32- / 64-byte boundaries
 int compact_stride(const Geom &g)
 {
     static const int forced = [] {
@@ -660,7 +660,9 @@ int compact_stride(const Geom &g)
         const int v = env ? std::atoi(env) : 0;
         return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 0;
     }();
-    const int a = forced ? forced : (g.M >= 512 ? 8 : 16);
+    // measured (profiles/r02_experiments.md): 8 at M = 512 (129 -> 136 columns), 4 at M = 256 (65 -> 68: padding to
+    // whole 16-column tiles, 80, costs more bytes than the alignment wins)
+    const int a = forced ? forced : (g.M >= 512 ? 8 : 4);
     return (g.N / 2 + 1 + a - 1) / a * a;
 }
 
