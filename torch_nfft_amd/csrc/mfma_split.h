@@ -38,5 +38,24 @@ __device__ __forceinline__ void split_product_pair(const float p0, const float a
         : "v"(p0), "v"(a0), "v"(p1), "v"(a1));
 }
 
+// One dword per active lane, global -> LDS without a register in between (LDS-DMA): lane l of the wave lands at
+// lds_wave_base + 4 l.  Issued through asm so that the compiler does not drain it (vmcnt(0)) at the next LDS read or
+// barrier; the consumer waits with wait_lds_dma() one pipeline step later.
+__device__ __forceinline__ void lds_dma_dword(const float *gsrc, const float *lds_wave_base)
+{
+    const unsigned lds = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds)
+                 : "memory");
+}
+__device__ __forceinline__ void wait_lds_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// all but the newest request (4 LDS-DMA instructions) have landed
+__device__ __forceinline__ void wait_lds_dma_but_newest() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+// workgroup barrier that leaves global traffic (LDS-DMA, flush atomics) in flight
+__device__ __forceinline__ void barrier_lds_only() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 
 } // namespace nfft
