@@ -26,7 +26,7 @@
 // flush of the padded tiles is what the scatter variant spends its time on (1.3 TB/s chip-wide for float atomics
 // against ~6 TB/s for stores); at the density of config C3 it is not (profiles/r02_flush_variants.txt).
 // Why: ds_add_f32 is unusable on gfx950 and the f64 LDS atomic bounds spread.hip at ~3.7 ms for 1e10 taps
-// (DESIGN.md section 4); here the taps are 0.49 PFLOP of matrix work and the kernel runs 1.7 ms at C3.
+// (DESIGN.md section 4); here the taps are 1.23 TFLOP of matrix work per launch (0.73 PFLOP/s) and the kernel runs 1.7 ms at C3.
 #include <algorithm>
 #include <climits>
 #include <cstdlib>
