@@ -439,7 +439,8 @@ fwd_axis1_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__rest
 // radix-8 stages then have 64 butterflies, one per lane, and RP rows' worth of loads are in flight.
 constexpr int kWaveCplx = 512;
 constexpr int kRowWaves = 4;       // waves per workgroup
-constexpr int kRowRounds = 2;      // rounds (of RP rows) per wave (2 measured best: 1, 4, 8 and 2 / 8 waves lose 3-25 %)
+constexpr int kRowRounds = 1;      // rounds (of RP rows) per wave (round 2, aligned strides: 1 round 0.194 ms at C3 / 12.0 ms at
+                                   // C4-share, 2 rounds 0.212 / 13.7, 4 and 8 worse; 2 or 8 waves per workgroup lose as well)
 
 // LDS index swizzle of the per-wave buffer: the butterflies of the later stages touch elements 4, 8 or 32 apart,
 // which without it land in the same banks (up to 16-way conflicts).  Bits 4..2 are XORed with bits 7..5 and bits
