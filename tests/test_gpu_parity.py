@@ -18,6 +18,8 @@ from oracle import ndft, nfft_ref
 pytestmark = pytest.mark.gpu
 
 T1 = 2e-5
+T1W = 2e-6  # matrix-core kernels (3-D grids of 64^3 and up, m <= 7): ~22-bit operands, observed 2e-7; a slip in the f16
+            # split (dropping a term costs ~5e-4, a mis-rounded hi part ~1e-5) must not pass
 T2 = {1: 2e-1, 2: 2e-2, 3: 3e-3, 4: 5e-4, 5: 1e-4, 6: 5e-5, 7: 3e-5, 8: 2e-5}
 
 
@@ -137,11 +139,12 @@ def test_column_fft_sizes_3d(tn, N, m):
     rng = np.random.default_rng(300 + N + m)
     n = 3000
     pos, batch, x = _random_problem(rng, 3, n, 1, (), True)
+    tol = T1W if N >= 32 else T1
     ya = tn.nfft_adjoint(dev(x), dev(pos), None, bandwidth=N, cutoff=m)
-    assert rel_l2(host(ya), nfft_ref.nfft_adjoint(x, pos, None, N=N, m=m)) < T1
+    assert rel_l2(host(ya), nfft_ref.nfft_adjoint(x, pos, None, N=N, m=m)) < tol
     xh = (rng.standard_normal((1, N, N, N)) + 1j * rng.standard_normal((1, N, N, N))).astype(np.complex64)
     yf = tn.nfft_forward(dev(xh), dev(pos), None, cutoff=m)
-    assert rel_l2(host(yf), nfft_ref.nfft_forward(xh, pos, None, m=m)) < T1
+    assert rel_l2(host(yf), nfft_ref.nfft_forward(xh, pos, None, m=m)) < tol
 
 
 @pytest.mark.parametrize("d", [1, 2, 3])
@@ -208,12 +211,12 @@ def test_edge_cases_wide_tiling(tn, N, m):
     ya = tn.nfft_adjoint(dev(x), dev(pos), dev(batch), bandwidth=N, cutoff=m)
     assert ya.shape == (5, N, N, N, 2)
     assert float(ya[1].abs().max()) == 0.0 and float(ya[2].abs().max()) == 0.0
-    assert rel_l2(host(ya), nfft_ref.nfft_adjoint(x, pos, batch, N=N, m=m)) < T1
+    assert rel_l2(host(ya), nfft_ref.nfft_adjoint(x, pos, batch, N=N, m=m)) < T1W
     yf = tn.nfft_forward(ya, dev(pos), dev(batch), cutoff=m)
-    assert rel_l2(host(yf), nfft_ref.nfft_forward(host(ya), pos, batch, m=m)) < T1
+    assert rel_l2(host(yf), nfft_ref.nfft_forward(host(ya), pos, batch, m=m)) < T1W
     # a single point
     y1 = tn.nfft_adjoint(dev(np.ones((1,), np.float32)), dev(pos[:1]), None, bandwidth=N, cutoff=m)
-    assert rel_l2(host(y1), nfft_ref.nfft_adjoint(np.ones((1,), np.float32), pos[:1], None, N=N, m=m)) < T1
+    assert rel_l2(host(y1), nfft_ref.nfft_adjoint(np.ones((1,), np.float32), pos[:1], None, N=N, m=m)) < T1W
 
 
 def test_many_small_point_sets_wide_tiling(tn):
@@ -685,5 +688,5 @@ def test_forward_many_columns_wave_per_column(tn, monkeypatch, C, complex_out, c
     ref = nfft_ref.nfft_forward(xh, pos, batch, m=m, real_output=not complex_out)
     assert y.shape == (n, C)
     for c in range(C):
-        assert rel_l2(y[:, c], ref[:, c]) < T1, c
+        assert rel_l2(y[:, c], ref[:, c]) < T1W, c
     assert rel_l2(y, ref) < 2e-6

@@ -46,15 +46,78 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-// tw[j] = exp(-2 pi i j / M), j < M/2, evaluated in double
-__global__ void twiddle_kernel(float2 *tw, int M)
+// tw[j] = exp(-2 pi i j / M), j < M/2: compile-time tables in the code object (one per grid size the passes support), so
+// that no transform has to launch a set-up kernel or keep a table in the caller's workspace.  Evaluated in double by
+// Taylor series (|x| < pi: 14 terms leave < 1e-15) and rounded once to float.
+constexpr double kPiD = 3.14159265358979323846264338327950288;
+constexpr double taylor_sin(double x)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < M / 2) {
-        double s, c;
-        sincospi(2.0 * (double)j / (double)M, &s, &c);
-        tw[j] = make_float2((float)c, (float)-s);
+    double term = x, sum = x;
+    for (int k = 1; k <= 16; ++k) {
+        term *= -x * x / (double)((2 * k) * (2 * k + 1));
+        sum += term;
     }
+    return sum;
+}
+constexpr double taylor_cos(double x)
+{
+    double term = 1.0, sum = 1.0;
+    for (int k = 1; k <= 16; ++k) {
+        term *= -x * x / (double)((2 * k - 1) * (2 * k));
+        sum += term;
+    }
+    return sum;
+}
+struct TwPair { float x, y; };
+template <int M>
+struct TwTable { TwPair v[M / 2]; };
+template <int M>
+constexpr TwTable<M> make_tw_table()
+{
+    TwTable<M> t{};
+    for (int j = 0; j < M / 2; ++j) {
+        // reduce to [0, pi/2]: cos(pi - a) = -cos a, sin(pi - a) = sin a  (j < M/2  =>  angle in [0, pi))
+        const bool upper = 4 * j > M;
+        const double a = 2.0 * kPiD * (double)(upper ? M / 2 - j : j) / (double)M;
+        const double c = taylor_cos(a), sn = taylor_sin(a);
+        t.v[j] = TwPair{(float)(upper ? -c : c), (float)-sn};
+    }
+    return t;
+}
+template <int M>
+__device__ const TwTable<M> kTwTable = make_tw_table<M>();
+
+template <int M>
+const float2 *tw_symbol()
+{
+    void *ptr = nullptr;
+    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(kTwTable<M>)) != hipSuccess) return nullptr;
+    return (const float2 *)ptr;
+}
+// device address of the table for grid size M on the current device (looked up once per device)
+const float2 *twiddle_table(int M)
+{
+    static std::atomic<const float2 *> cache[kMaxDevices][7];
+    const int dev = current_device();
+    int slot = 0;
+    while ((16 << slot) < M) ++slot;
+    if (slot > 6 || (16 << slot) != M) return nullptr;
+    if (dev < kMaxDevices) {
+        const float2 *p = cache[dev][slot].load(std::memory_order_acquire);
+        if (p) return p;
+    }
+    const float2 *p = nullptr;
+    switch (M) {
+    case 16: p = tw_symbol<16>(); break;
+    case 32: p = tw_symbol<32>(); break;
+    case 64: p = tw_symbol<64>(); break;
+    case 128: p = tw_symbol<128>(); break;
+    case 256: p = tw_symbol<256>(); break;
+    case 512: p = tw_symbol<512>(); break;
+    case 1024: p = tw_symbol<1024>(); break;
+    }
+    if (p && dev < kMaxDevices) cache[dev][slot].store(p, std::memory_order_release);
+    return p;
 }
 
 // In-place decimation-in-frequency FFT along the row index of buf[M][NC], radix 8 / 4 stages with the butterflies in
@@ -718,13 +781,8 @@ bool colfft_supported(const Geom &g)
 
 int64_t colfft_scratch_bytes(const Geom &g, int64_t nplanes)
 {
-    // T[plane][M][N+1][N/2+1] complex + twiddle table
+    // T[plane][M][N+1][KS] complex (+ room that used to hold a twiddle table; the workspace contract keeps its size)
     return align_up(nplanes * (int64_t)g.M * (g.N + 1) * compact_stride(g) * 8, 256) + align_up((int64_t)g.M * 4, 256);
-}
-
-static float2 *twiddle_ptr(const Geom &g, int64_t nplanes, void *scratch)
-{
-    return (float2 *)((char *)scratch + align_up(nplanes * (int64_t)g.M * (g.N + 1) * compact_stride(g) * 8, 256));
 }
 
 int launch_colfft_adjoint(const Geom &g, const float2 *spec, bool compact, void *scratch, int64_t scratch_planes,
@@ -733,8 +791,8 @@ int launch_colfft_adjoint(const Geom &g, const float2 *spec, bool compact, void 
 {
     if (nplanes <= 0) return 0;
     float2 *T = (float2 *)scratch;
-    float2 *tw = twiddle_ptr(g, scratch_planes, scratch);
-    hipLaunchKernelGGL(twiddle_kernel, dim3((g.M / 2 + 255) / 256), dim3(256), 0, stream, tw, g.M);
+    const float2 *tw = twiddle_table(g.M);
+    if (!tw) { set_error("no twiddle table for this grid size"); return 4; }
     {
         const ColGeom cg = make_col_geom(g, false, compact);
         const dim3 grid((cg.KC + cg.NC - 1) / cg.NC, g.M, (unsigned)nplanes);
@@ -770,8 +828,8 @@ int launch_colfft_forward(const Geom &g, const void *xhat, void *scratch, int64_
 {
     if (nplanes <= 0) return 0;
     float2 *T = (float2 *)scratch;
-    float2 *tw = twiddle_ptr(g, scratch_planes, scratch);
-    hipLaunchKernelGGL(twiddle_kernel, dim3((g.M / 2 + 255) / 256), dim3(256), 0, stream, tw, g.M);
+    const float2 *tw = twiddle_table(g.M);
+    if (!tw) { set_error("no twiddle table for this grid size"); return 4; }
     const ColGeom cg = make_col_geom(g, false, compact);
     const size_t lds = col_lds_bytes(cg, false);
     const int ppc = real_output ? 1 : 2;
@@ -830,8 +888,8 @@ int launch_row_r2c(const Geom &g, const float *grid, void *scratch, int64_t scra
                    float2 *spec, hipStream_t stream)
 {
     if (nplanes <= 0) return 0;
-    float2 *tw = twiddle_ptr(g, scratch_planes, scratch);
-    hipLaunchKernelGGL(twiddle_kernel, dim3((g.M / 2 + 255) / 256), dim3(256), 0, stream, tw, g.M);
+    const float2 *tw = twiddle_table(g.M);
+    if (!tw) { set_error("no twiddle table for this grid size"); return 4; }
     return launch_rows(false, g, nplanes, tw, grid, spec, stream);
 }
 
@@ -839,7 +897,8 @@ int launch_row_c2r(const Geom &g, const float2 *spec, void *scratch, int64_t scr
                    float *grid, hipStream_t stream)
 {
     if (nplanes <= 0) return 0;
-    float2 *tw = twiddle_ptr(g, scratch_planes, scratch);  // written by launch_colfft_forward on the same stream
+    const float2 *tw = twiddle_table(g.M);
+    if (!tw) { set_error("no twiddle table for this grid size"); return 4; }
     return launch_rows(true, g, nplanes, tw, spec, grid, stream);
 }
 
