@@ -145,6 +145,7 @@ int owned_override();  // api.hip: -1 auto, 0 never, 1 whenever supported
 inline bool choose_owned(int dim, int64_t N, int64_t m, int64_t n, int64_t B, double occupied)
 {
     if (!owned_supported(dim, N, m)) return false;
+    if (n >= (int64_t(1) << 28)) return false;  // the owned plan holds up to 4 n entries behind 32-bit offsets
     const int ov = owned_override();
     if (ov >= 0) return ov != 0;
     const double cells = 8.0 * (double)N * (double)N * (double)N * (double)(B > 0 ? B : 1) * occupied;
