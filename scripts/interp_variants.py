@@ -9,7 +9,7 @@ p = lambda t: ctypes.c_void_p(t.data_ptr())
 d, N, m, n = 3, int(os.environ.get("NBAND", 256)), int(os.environ.get("M_CUT", 4)), int(os.environ.get("NPTS", 10_000_000))
 prob = _lib.Problem(d, n, 1, 1, N, m)
 gen = torch.Generator(device="cuda").manual_seed(1)
-pos = torch.rand((n, d), generator=gen, device="cuda") - 0.5
+pos = (torch.rand((n, d), generator=gen, device="cuda") - 0.5) * float(os.environ.get("SCALE", 1.0))
 plan = torch.empty(lib.nfft_hip_plan_bytes(ctypes.byref(prob)), dtype=torch.uint8, device="cuda")
 s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 _lib.check(lib.nfft_hip_plan_points(ctypes.byref(prob), p(pos), None, p(plan), plan.numel(), s))

@@ -162,6 +162,7 @@ int gather_any(const Geom &g, const PlanLayout &L, const void *plan, const float
         return env && env[0] == 'l';
     }();
     if (!lds_only && interp_cols_supported(g, Cr)) return launch_interp_cols(g, L, plan, grid, n, Cr, plane0, nplanes, yr, s);
+    if (!lds_only && interp_stream_supported(g) && interp_stream_pays(g, L, n)) return launch_interp_stream(g, L, plan, grid, n, Cr, plane0, nplanes, yr, s);
     if (!lds_only && interp_mfma_supported(g)) return launch_interp_mfma(g, L, plan, grid, n, Cr, plane0, nplanes, yr, s);
     return launch_interp(g, L, plan, grid, n, Cr, plane0, nplanes, yr, s);
 }

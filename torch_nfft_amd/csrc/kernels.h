@@ -34,6 +34,11 @@ bool interp_mfma_supported(const Geom &g);
 int launch_interp_mfma(const Geom &g, const PlanLayout &L, const void *plan, const float *grid, int64_t n, int64_t Cr,
                        int64_t plane0, int64_t nplanes, float *yr, hipStream_t stream);
 
+// streamed variant (interp_stream.hip): producer waves feed the plane ring, consumer waves pull blocks from a queue
+bool interp_stream_supported(const Geom &g);
+bool interp_stream_pays(const Geom &g, const PlanLayout &L, int64_t n);  // big work items only
+int launch_interp_stream(const Geom &g, const PlanLayout &L, const void *plan, const float *grid, int64_t n, int64_t Cr,
+                         int64_t plane0, int64_t nplanes, float *yr, hipStream_t stream);
 // several coefficient columns per workgroup, one wave per column (interp_cols.hip): the point-side operands are built
 // once for 8 columns, each wave streams its own column's planes from global memory
 bool interp_cols_supported(const Geom &g, int64_t Cr);
