@@ -245,3 +245,34 @@ def test_config_c5_fastsum_1m_x_1m(tn):
     d2 = ((tgt[sel, None, :].double() - src[None, :, :].double()) ** 2).sum(-1)
     exact = (torch.exp(-d2 / sigma ** 2) * x.double()[None, :]).sum(1)
     assert rel_l2(y[sel].cpu().numpy(), exact.cpu().numpy()) < 1e-3
+
+
+def test_streamed_interpolation_clustered_8m(tn):
+    """8e6 points in 8 tight Gaussian clusters on a 256^3 grid: the plan's work items are big enough for the streamed
+    (producer / consumer) interpolation kernel, most of them are overflow pieces, many chunks between clusters are
+    empty (the producers skip planes nobody needs).  Forward of a sparse spectrum vs the exact sums on a sample of
+    points, run twice (the kernel has no atomics: the two runs must agree bitwise), and adjointness with the adjoint."""
+    N, m, n = 128, 4, 8_000_000
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    centres = torch.rand((8, 3), generator=gen, device="cuda") - 0.5
+    which = torch.randint(0, 8, (n,), generator=gen, device="cuda")
+    pos = centres[which] + 0.03 * torch.randn((n, 3), generator=gen, device="cuda")
+    pos = pos - torch.floor(pos + 0.5)
+    rng = np.random.default_rng(78)
+    f = rng.integers(-N // 2, N // 2, size=(6, 3))
+    vals = (rng.standard_normal(6) + 1j * rng.standard_normal(6)).astype(np.complex64)
+    xh = torch.zeros((1, N, N, N), dtype=torch.complex64, device="cuda")
+    for fr, v in zip(f, vals):
+        xh[(0,) + tuple(fr + N // 2)] += complex(v)
+    y1 = tn.nfft_forward(xh, pos, None, cutoff=m)
+    y2 = tn.nfft_forward(xh, pos, None, cutoff=m)
+    assert torch.equal(y1, y2)
+    idx = rng.integers(0, n, size=8192)
+    p = pos[idx].cpu().numpy().astype(np.float64)
+    exact = (np.exp(-2j * np.pi * (p @ f.T.astype(np.float64))) * vals[None, :].astype(np.complex128)).sum(1)
+    assert rel_l2(y1[idx].cpu().numpy(), exact) < T2_M4
+    x = torch.randn((n,), generator=gen, device="cuda")
+    ya = tn.nfft_adjoint(x, pos, None, bandwidth=N, cutoff=m)
+    lhs = torch.sum(ya * xh.conj())
+    rhs = torch.sum(x.to(torch.complex64) * y1.conj())
+    assert abs(complex(lhs) - complex(rhs)) < 1e-4 * abs(complex(lhs)) + 1e-2

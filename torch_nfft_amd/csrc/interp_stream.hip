@@ -7,7 +7,8 @@
 // chunk (all waves wait for the loads), barrier, every wave takes one block, barrier ... -- measured at config C3:
 // staging alone 0.44 ms, compute alone 1.30 ms, nothing overlaps, and a chunk's ~19 blocks leave 3 for a second round
 // (profiles/r02_experiments.md).  Here
-//   * 3 producer waves stage planes continuously: wave p takes the planes z = p (mod 3) of the item's
+//   * 3 producer waves stage planes continuously: wave p takes the ring slots s = p (mod 3), i.e. the planes z with
+//     (z & 15) % 3 == p, of the item's
 //     sweep, loads the padded 32 x 64 tile (the next plane's loads are in flight while the current one is converted),
 //     scales it by its own power of two, f16-splits it into the ring slot z & 15 and publishes ready[slot] = z;
 //   * 13 consumer waves pull blocks from an LDS counter.  A block belongs to one chunk of 17 - (2m+2) slabs, so its
@@ -183,16 +184,18 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
                 }
             }
         };
-        // next plane of this producer's sequence that some chunk needs
+        // Next plane >= z of this producer's sequence that some chunk needs.  A ring slot belongs to ONE producer
+        // (slot mod kIsProducers): planes z and z + 16 share a slot, and only one wave staging them in order keeps a
+        // late plane z from overwriting (and un-publishing) plane z + 16.
         auto next_needed = [&](int z) {
-            while (z < z_end && !needed(z)) z += kIsProducers;
+            while (z < z_end && (((z & (kIsRing - 1)) % kIsProducers) != p || !needed(z))) ++z;
             return z;
         };
-        int z = next_needed(z_begin + p);
+        int z = next_needed(z_begin);
         f32x4 cur[8], nxt[8];
         if (z < z_end) load_plane(z, cur);
         while (z < z_end) {
-            const int zn = next_needed(z + kIsProducers);
+            const int zn = next_needed(z + 1);
             if (zn < z_end) load_plane(zn, nxt);
             // power-of-two scale of the tile; odd planes are stored negated (un-negated through pinv): the MFMA
             // accumulation truncates with a small sign-independent bias that cancels over alternating planes
