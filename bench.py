@@ -35,7 +35,7 @@ VALU_FMA_PER_S = 78.65e12      # 157.3 TFLOP/s fp32 vector = 78.65e12 FMA/s
 MFMA_F16_FLOPS = 2.5e15        # dense f16 matrix peak (MI355X_MICROARCH.md)
 ARITHMETIC = ("fp32 in / fp32 out; window sums on v_mfma_f32_32x32x16_f16 with two-way f16-split operands "
               "(hi*hi + hi*lo + lo*hi, ~22 significant bits) and fp32 accumulation; FFT and roll-off in fp32")
-KERNEL_SOURCES = ("spread_mfma.hip", "spread_own.hip", "common.h", "mfma_split.h", "window.h")
+KERNEL_SOURCES = ("spread_mfma.hip", "common.h", "mfma_split.h", "window.h")
 
 
 def parse():
