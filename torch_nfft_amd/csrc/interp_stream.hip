@@ -276,18 +276,20 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
             const int z_last = __builtin_amdgcn_readlane(c0, nvalid - 1) + m + 1;
             if (lane == 0) lds_store(&L.progress[wave], z_first);  // planes below are no longer mine
 
-            // B fragments: psi2 of my point on the padded columns 16 ks + 8 h + jj (zero outside the window)
+            // B fragments: psi2 of my point on the padded columns 16 ks + 8 h + jj (zero outside the window).
+            // d = f2 + m - l2 with l2 = column - o2: one subtraction from a per-lane base per value; the scale 2^11 of
+            // the operand rides in the exponent; padding lanes get a base far outside every window.
             u32x4 bh[4], bl[4];
-            const int o2 = c2 - tb2;  // padded column of tap 0
+            const int o2h = c2 - tb2 - 8 * h;  // padded column of tap 0, minus this lane's column offset
+            const float dbase2 = valid ? f2 + (float)(m + o2h) : 1.0e4f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 float w[8];
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
-                    const int l2 = 16 * ks + 8 * h + jj - o2;
-                    const float d = f2 + (float)(m - l2);
-                    const float ev = __builtin_amdgcn_exp2f(sc * d * d) * kOpScale;
-                    w[jj] = (valid && (unsigned)l2 < (unsigned)W) ? ev : 0.0f;
+                    const float d = dbase2 - (float)(16 * ks + jj);
+                    const float ev = __builtin_amdgcn_exp2f(fmaf(d * d, sc, 11.0f));  // exp2(sc d^2) * kOpScale
+                    w[jj] = (unsigned)(16 * ks + jj - o2h) < (unsigned)W ? ev : 0.0f;
                 }
                 unsigned h0, h1, h2, h3, q0, q1, q2, q3;
                 split_pair(w[0], w[1], h0, q0);
@@ -297,16 +299,16 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
                 bh[ks] = u32x4{h0, h1, h2, h3};
                 bl[ks] = u32x4{q0, q1, q2, q3};
             }
-            // psi1 of my point on the 16 rows this lane holds of every T_z (MFMA result layout)
+            // psi1 of my point on the 16 rows this lane holds of every T_z (MFMA result layout): row = r + 8 q + 4 h
             float w1[16];
-            const int o1 = c1 - tb1;
+            const int o1h = c1 - tb1 - 4 * h;
+            const float dbase1 = f1 + (float)(m + o1h);
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                const int l1 = row - o1;
-                const float d = f1 + (float)(m - l1);
+                const int rq = (reg & 3) + 8 * (reg >> 2);
+                const float d = dbase1 - (float)rq;
                 const float ev = __builtin_amdgcn_exp2f(sc * d * d);
-                w1[reg] = (unsigned)l1 < (unsigned)W ? ev : 0.0f;
+                w1[reg] = (unsigned)(rq - o1h) < (unsigned)W ? ev : 0.0f;
             }
 
             float y = 0.0f;
