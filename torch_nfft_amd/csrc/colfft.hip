@@ -605,11 +605,19 @@ row_r2c_kernel(int KC, int KS, int64_t nrows, const float2 *__restrict__ tw, con
         const int64_t row = row0 + (int64_t)r * RP;
         if (row >= nrows) break;
         const int nr = (int)min((int64_t)RP, nrows - row);  // rows of this round (all RP except at the very end)
-        const float2 *src = (const float2 *)(grid + row * M);
+        // 16 bytes per lane: the rows arrive in half as many load instructions (C3: 0.198 -> 0.173 ms per pass)
+        const float4 *src4 = (const float4 *)(grid + row * M);
+        float4 v4[kWaveCplx / 128];
 #pragma unroll
-        for (int n0 = 0; n0 < kWaveCplx; n0 += 64) {
-            const int n = n0 + lane;
-            z[zsw(n)] = n < nr * L ? src[n] : make_float2(0.f, 0.f);
+        for (int q = 0; q < kWaveCplx / 128; ++q) {
+            const int n2 = q * 64 + lane;  // pair index: elements 2 n2, 2 n2 + 1
+            v4[q] = 2 * n2 < nr * L ? src4[n2] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < kWaveCplx / 128; ++q) {
+            const int n2 = q * 64 + lane;
+            z[zsw(2 * n2)] = make_float2(v4[q].x, v4[q].y);
+            z[zsw(2 * n2 + 1)] = make_float2(v4[q].z, v4[q].w);
         }
         wave_fft<false, LOGL>(z, S.tw, lane);
         for (int rr = 0; rr < nr; ++rr) {
@@ -660,12 +668,16 @@ row_c2r_kernel(int KC, int KS, int64_t nrows, const float2 *__restrict__ tw, con
             z[zsw(n)] = make_float2(sum.x - wd.y, sum.y + wd.x);  // sum + i w dif
         }
         wave_fft<true, LOGL>(z, S.tw, lane);
-        float2 *dst = (float2 *)(grid + row * M);
+        float4 *dst4 = (float4 *)(grid + row * M);
 #pragma unroll
-        for (int n0 = 0; n0 < kWaveCplx; n0 += 64) {
-            const int n = n0 + lane;
-            const int rr = n >> LOGL, k = n & (L - 1);
-            if (rr < nr) dst[n] = z[zsw(rr * L + S.rev[k])];
+        for (int q = 0; q < kWaveCplx / 128; ++q) {
+            const int n2 = q * 64 + lane;
+            const int na = 2 * n2, nb = 2 * n2 + 1;
+            const int rr = na >> LOGL;
+            if (rr < nr) {
+                const float2 a = z[zsw(rr * L + S.rev[na & (L - 1)])], b = z[zsw(rr * L + S.rev[nb & (L - 1)])];
+                dst4[n2] = make_float4(a.x, a.y, b.x, b.y);
+            }
         }
     }
 }
