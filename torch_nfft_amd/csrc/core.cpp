@@ -136,7 +136,10 @@ struct PlanCache {
             e = PlanEntry();
         }
     }
-} g_cache;
+};
+// (never destroyed: at process exit the tensors it holds would otherwise be released after torch's allocator and
+// the HIP runtime have been torn down)
+PlanCache &g_cache = *new PlanCache;
 
 at::Tensor get_plan(const Points &p, const nfft_hip_problem &q)
 {
