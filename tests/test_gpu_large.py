@@ -276,3 +276,29 @@ def test_streamed_interpolation_clustered_8m(tn):
     lhs = torch.sum(ya * xh.conj())
     rhs = torch.sum(x.to(torch.complex64) * y1.conj())
     assert abs(complex(lhs) - complex(rhs)) < 1e-4 * abs(complex(lhs)) + 1e-2
+
+
+@pytest.mark.parametrize("m,nsets", [(2, 1), (5, 1), (4, 2)])
+def test_streamed_interpolation_other_cutoffs(tn, m, nsets):
+    """The streamed interpolation kernel with other window widths (chunks of 11 and 5 slabs instead of 7) and with two
+    point sets: 6e6 / 12e6 uniform points on a 256^3 grid (big enough work items to select it); forward of a sparse
+    spectrum vs the exact sums on a sample of points."""
+    N = 128
+    n = 6_000_000 * nsets
+    gen = torch.Generator(device="cuda").manual_seed(90 + m + nsets)
+    pos = torch.rand((n, 3), generator=gen, device="cuda") - 0.5
+    batch = None if nsets == 1 else (torch.arange(n, device="cuda") >= n // 2).to(torch.int64)
+    rng = np.random.default_rng(91 + m)
+    f = rng.integers(-N // 2, N // 2, size=(5, 3))
+    vals = (rng.standard_normal((nsets, 5)) + 1j * rng.standard_normal((nsets, 5))).astype(np.complex64)
+    xh = torch.zeros((nsets, N, N, N), dtype=torch.complex64, device="cuda")
+    for b in range(nsets):
+        for fr, v in zip(f, vals[b]):
+            xh[(b,) + tuple(fr + N // 2)] += complex(v)
+    y = tn.nfft_forward(xh, pos, batch, cutoff=m)
+    idx = rng.integers(0, n, size=8192)
+    p = pos[idx].cpu().numpy().astype(np.float64)
+    bsel = np.zeros(idx.shape[0], np.int64) if batch is None else batch[idx].cpu().numpy()
+    exact = (np.exp(-2j * np.pi * (p @ f.T.astype(np.float64))) * vals[bsel].astype(np.complex128)).sum(1)
+    tol = {2: 2e-2, 4: 5e-4, 5: 1e-4}[m]
+    assert rel_l2(y[idx].cpu().numpy(), exact) < tol

@@ -662,14 +662,16 @@ print("RESULT", err, bool((y == y2).all()))
 
 # ----------------------------------------------------------------------------- wave-per-column interpolation
 
-@pytest.mark.parametrize("C,complex_out,chunk_planes", [(5, True, None), (3, False, None), (9, False, 7), (4, True, 5)])
-def test_forward_many_columns_wave_per_column(tn, monkeypatch, C, complex_out, chunk_planes):
+@pytest.mark.parametrize("C,complex_out,chunk_planes,m", [(5, True, None, 4), (3, False, None, 4), (9, False, 7, 4),
+                                                          (4, True, 5, 4), (6, False, None, 2), (4, False, None, 6),
+                                                          (2, True, None, 7)])
+def test_forward_many_columns_wave_per_column(tn, monkeypatch, C, complex_out, chunk_planes, m):
     """From 4 real planes per point set the forward gather runs one wave per column (interp_cols.hip): column counts
     that do not fill the last group of 8, chunks of planes that start in the middle of a group and of a point set,
     a pencil holding far more than one group of 384 points (several plane sweeps), empty point sets, points on the
     torus boundary -- forward transform against the float64 algorithm restatement, per column."""
-    rng = np.random.default_rng(600 + C)
-    N, m, B = 32, 4, 4
+    rng = np.random.default_rng(600 + C + m)
+    N, B = 32, 4
     n_dense, n_rest = 6000, 3000
     dense = (0.02 * rng.standard_normal((n_dense, 3)) + np.array([0.11, -0.23, 0.37])).astype(np.float32)
     edge = np.array([[-0.5, -0.5, -0.5], [0.49999997, 0.49999997, 0.49999997], [0.0, 0.0, 0.0]], np.float32)
