@@ -42,7 +42,7 @@ PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)
     L.off_hscan = o;   o = align_up(o + (L.two_level ? scan_items * 4 : 0), 256);
     L.off_tmp = o;     o = align_up(o + (L.two_level ? L.cap * 16 : 0), 256);
     // second level: per (first-level bin, part) counts of the fine keys
-    L.off_hist2 = o;   o = align_up(o + (L.two_level ? L.npencils * kSort2Parts * (int64_t)g.l1bins * g.SB * 4 : 0), 256);
+    L.off_hist2 = o;   o = align_up(o + (L.two_level ? L.npencils * kSort2Parts * (int64_t)g.l1bins * g.SB * g.QS * 4 : 0), 256);
     L.total = o;
     return L;
 }
@@ -223,6 +223,12 @@ __device__ __forceinline__ int fine_key(const Geom &g, const float4 rec, const i
         split_cell(rec.z, g.M, cell[2], fr);
         key = key * g.SB + sub_of_cells(g, cell);
     }
+    if (g.QS > 1) {
+        // ordering-only: quarter of the pencil's width the point's column lies in
+        split_cell(rec.z, g.M, cell[2], fr);
+        const int col = cell[2] % g.Ta[2];
+        key = key * g.QS + min(g.QS - 1, col * g.QS / g.Ta[2]);
+    }
     return key;
 }
 
@@ -249,7 +255,7 @@ sort2_count_kernel(Geom g, int nblocks, const int *__restrict__ hscan, const flo
     const int l1 = blockIdx.x, part = blockIdx.y;
     const int pencil = l1 / g.l1seg, sg = l1 - pencil * g.l1seg;
     const int bin_lo = sg * g.l1bins;
-    const int nt0 = (min(g.np0, bin_lo + g.l1bins) - bin_lo) * g.SB;  // fine keys of this first-level bin
+    const int nt0 = (min(g.np0, bin_lo + g.l1bins) - bin_lo) * g.SB * g.QS;  // fine keys of this first-level bin
     int p0, r0, r1;
     sort2_range(hscan, l1, nblocks, part, p0, r0, r1);
     for (int i = threadIdx.x; i < nt0; i += kSortThreads) lds2[i] = 0;
@@ -266,7 +272,7 @@ sort2_count_kernel(Geom g, int nblocks, const int *__restrict__ hscan, const flo
             if (j0 + q * kSortThreads < r1) atomicAdd(&lds2[fine_key(g, rec[q], bin_lo)], 1);
     }
     __syncthreads();
-    int *out = hist2 + ((int64_t)l1 * kSort2Parts + part) * g.l1bins * g.SB;
+    int *out = hist2 + ((int64_t)l1 * kSort2Parts + part) * g.l1bins * g.SB * g.QS;
     for (int i = threadIdx.x; i < nt0; i += kSortThreads) out[i] = lds2[i];
 }
 
@@ -279,12 +285,13 @@ sort2_scatter_kernel(Geom g, int npencils, int nblocks, const int *__restrict__ 
     const int l1 = blockIdx.x, part = blockIdx.y;
     const int pencil = l1 / g.l1seg, sg = l1 - pencil * g.l1seg;
     const int bin_lo = sg * g.l1bins;
-    const int nt0 = (min(g.np0, bin_lo + g.l1bins) - bin_lo) * g.SB;
+    const int nt0 = (min(g.np0, bin_lo + g.l1bins) - bin_lo) * g.SB * g.QS;
     const int64_t obase = ((int64_t)pencil * g.np0 + bin_lo) * g.SB;   // first entry of these keys in the offsets table
+                                                                        // (one entry per QS ordering keys)
     int p0, r0, r1;
     sort2_range(hscan, l1, nblocks, part, p0, r0, r1);
-    const int *table = hist2 + (int64_t)l1 * kSort2Parts * g.l1bins * g.SB;
-    const int kstride = g.l1bins * g.SB;
+    const int *table = hist2 + (int64_t)l1 * kSort2Parts * g.l1bins * g.SB * g.QS;
+    const int kstride = g.l1bins * g.SB * g.QS;
     // exclusive scan over the keys of (total over the parts) by one wave; cursor = p0 + keys before + parts before
     if (threadIdx.x < 64) {
         int carry = 0;
@@ -307,11 +314,11 @@ sort2_scatter_kernel(Geom g, int npencils, int nblocks, const int *__restrict__ 
             if (idx < nt0) {
                 const int excl = carry + incl - tot;
                 lds2[idx] = p0 + excl + before;
-                if (part == 0) offsets[obase + idx] = p0 + excl;
+                if (part == 0 && idx % g.QS == 0) offsets[obase + idx / g.QS] = p0 + excl;
             }
             carry += __shfl(incl, 63);
         }
-        if (part == 0 && l1 == npencils - 1 && threadIdx.x == 0) offsets[obase + nt0] = p0 + carry;  // = entries
+        if (part == 0 && l1 == npencils - 1 && threadIdx.x == 0) offsets[obase + nt0 / g.QS] = p0 + carry;  // = entries
     }
     __syncthreads();
     for (int j0 = r0 + threadIdx.x; j0 < r1; j0 += kSortThreads * 8) {
@@ -454,7 +461,7 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
         hipLaunchKernelGGL(sort1_scatter_kernel, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
                            npencils, nblocks, hscan, tmp);
         int *hist2 = (int *)(base + L.off_hist2);
-        const size_t lds2 = (size_t)g.l1bins * g.SB * 4;
+        const size_t lds2 = (size_t)g.l1bins * g.SB * g.QS * 4;
         hipLaunchKernelGGL(sort2_count_kernel, dim3(npencils, kSort2Parts), dim3(kSortThreads), lds2, stream, g, nblocks,
                            hscan, tmp, hist2);
         hipLaunchKernelGGL(sort2_scatter_kernel, dim3(npencils, kSort2Parts), dim3(kSortThreads), lds2, stream, g, npencils,

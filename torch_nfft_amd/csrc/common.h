@@ -86,10 +86,15 @@ struct Geom {
     // plan is sorted down to (tile, sub-block), so a tile's points are contiguous AND grouped by sub-block.
     // tile_offsets has one entry per (tile, sub-block): index tile * SB + s1 * sb2 + s2.
     int sb1, sb2, SB;
+    // Ordering-only sub-key of the second-level sort (no entry in tile_offsets; opt-in, NFFT_HIP_COLORDER=1): the
+    // points of a slab of a wide pencil are ordered by column quarter, so that a block of 32 consecutive points touches few 16-column groups of the
+    // padded tile and the gather kernels can skip the MFMA k-steps whose B fragments are all zero.
+    int QS;
     int64_t cells; // M^dim
 };
 
 inline bool owned_supported(int dim, int64_t N, int64_t m);
+bool column_order_enabled();  // api.hip: NFFT_HIP_COLORDER=1 turns the column ordering inside slabs on
 
 inline Geom make_geom(int dim, int64_t N, int64_t m, bool owned = false)
 {
@@ -131,6 +136,7 @@ inline Geom make_geom(int dim, int64_t N, int64_t m, bool owned = false)
     g.sb1 = sub ? g.Ta[1] / kSub : 1;
     g.sb2 = sub ? g.Ta[2] / kSub : 1;
     g.SB = g.sb1 * g.sb2;
+    g.QS = (g.wide && !g.owned && g.SB == 1 && column_order_enabled()) ? 4 : 1;
     return g;
 }
 

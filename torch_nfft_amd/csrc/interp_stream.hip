@@ -299,6 +299,12 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
                 bh[ks] = u32x4{h0, h1, h2, h3};
                 bl[ks] = u32x4{q0, q1, q2, q3};
             }
+            // 16-column groups of the padded tile that no point of the block touches: their B fragments are all zero and
+            // the k-step is skipped (the plan orders the points of a slab by column quarter: ~2.5 of 4 groups are live)
+            bool live[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                live[ks] = __builtin_amdgcn_ballot_w64((bh[ks].x | bh[ks].y | bh[ks].z | bh[ks].w) != 0u) != 0ull;
             // psi1 of my point on the 16 rows this lane holds of every T_z (MFMA result layout): row = r + 8 q + 4 h
             float w1[16];
             const int o1h = c1 - tb1 - 4 * h;
@@ -325,6 +331,7 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
                 f32x16 acc = 0.0f;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
+                    if (!live[ks]) continue;  // wave-uniform
                     const f16x8 ah = L.frag[slot][ks][0][lane], al = L.frag[slot][ks][1][lane];
                     const f16x8 bhk = __builtin_bit_cast(f16x8, bh[ks]), blk2 = __builtin_bit_cast(f16x8, bl[ks]);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhk, acc, 0, 0, 0);
