@@ -99,13 +99,11 @@ SpreadMode spread_mode()
     return mode;
 }
 
-bool column_order_enabled()
+bool column_groups_enabled()
 {
     static const bool on = [] {
-        // off by default: at C3 it takes 0.045 ms off the interpolation (k-steps whose B fragments are all zero are
-        // skipped) and adds 0.10 ms to the plan; worth it only when one plan serves many transforms
-        const char *env = std::getenv("NFFT_HIP_COLORDER");
-        return env && env[0] == '1';
+        const char *env = std::getenv("NFFT_HIP_COLGROUPS");
+        return !(env && env[0] == '0');
     }();
     return on;
 }

@@ -42,7 +42,9 @@ PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)
     L.off_hscan = o;   o = align_up(o + (L.two_level ? scan_items * 4 : 0), 256);
     L.off_tmp = o;     o = align_up(o + (L.two_level ? L.cap * 16 : 0), 256);
     // second level: per (first-level bin, part) counts of the fine keys
-    L.off_hist2 = o;   o = align_up(o + (L.two_level ? L.npencils * kSort2Parts * (int64_t)g.l1bins * g.SB * g.QS * 4 : 0), 256);
+    L.off_hist2 = o;   o = align_up(o + (L.two_level ? L.npencils * kSort2Parts * (int64_t)g.l1bins * g.SB * g.CG * 4 : 0), 256);
+    L.grouped = L.two_level && g.CG == 3;
+    L.off_groups = o;  o = align_up(o + (L.grouped ? L.ntiles * 2 * 4 : 0), 256);
     L.total = o;
     return L;
 }
@@ -223,11 +225,10 @@ __device__ __forceinline__ int fine_key(const Geom &g, const float4 rec, const i
         split_cell(rec.z, g.M, cell[2], fr);
         key = key * g.SB + sub_of_cells(g, cell);
     }
-    if (g.QS > 1) {
-        // ordering-only: quarter of the pencil's width the point's column lies in
+    if (g.CG > 1) {
+        // ordering inside the slab: column group of the point's window in the padded tile
         split_cell(rec.z, g.M, cell[2], fr);
-        const int col = cell[2] % g.Ta[2];
-        key = key * g.QS + min(g.QS - 1, col * g.QS / g.Ta[2]);
+        key = key * g.CG + column_group(cell[2] % g.Ta[2], g.W);
     }
     return key;
 }
@@ -255,7 +256,7 @@ sort2_count_kernel(Geom g, int nblocks, const int *__restrict__ hscan, const flo
     const int l1 = blockIdx.x, part = blockIdx.y;
     const int pencil = l1 / g.l1seg, sg = l1 - pencil * g.l1seg;
     const int bin_lo = sg * g.l1bins;
-    const int nt0 = (min(g.np0, bin_lo + g.l1bins) - bin_lo) * g.SB * g.QS;  // fine keys of this first-level bin
+    const int nt0 = (min(g.np0, bin_lo + g.l1bins) - bin_lo) * g.SB * g.CG;  // fine keys of this first-level bin
     int p0, r0, r1;
     sort2_range(hscan, l1, nblocks, part, p0, r0, r1);
     for (int i = threadIdx.x; i < nt0; i += kSortThreads) lds2[i] = 0;
@@ -272,40 +273,46 @@ sort2_count_kernel(Geom g, int nblocks, const int *__restrict__ hscan, const flo
             if (j0 + q * kSortThreads < r1) atomicAdd(&lds2[fine_key(g, rec[q], bin_lo)], 1);
     }
     __syncthreads();
-    int *out = hist2 + ((int64_t)l1 * kSort2Parts + part) * g.l1bins * g.SB * g.QS;
+    int *out = hist2 + ((int64_t)l1 * kSort2Parts + part) * g.l1bins * g.SB * g.CG;
     for (int i = threadIdx.x; i < nt0; i += kSortThreads) out[i] = lds2[i];
 }
 
 __global__ void __launch_bounds__(kSortThreads)
 sort2_scatter_kernel(Geom g, int npencils, int nblocks, const int *__restrict__ hscan, const float4 *__restrict__ tmp,
-                     const int *__restrict__ hist2, int *__restrict__ offsets, int *__restrict__ perm,
-                     float *__restrict__ spos)
+                     const int *__restrict__ hist2, int *__restrict__ offsets, int *__restrict__ groups,
+                     int *__restrict__ perm, float *__restrict__ spos)
 {
-    extern __shared__ int lds2[];  // [fine keys]: totals -> this part's cursors
+    extern __shared__ int lds2[];  // [fine keys] this part's cursors, [fine keys] totals over the parts
     const int l1 = blockIdx.x, part = blockIdx.y;
     const int pencil = l1 / g.l1seg, sg = l1 - pencil * g.l1seg;
     const int bin_lo = sg * g.l1bins;
-    const int nt0 = (min(g.np0, bin_lo + g.l1bins) - bin_lo) * g.SB * g.QS;
+    const int nt0 = (min(g.np0, bin_lo + g.l1bins) - bin_lo) * g.SB * g.CG;
     const int64_t obase = ((int64_t)pencil * g.np0 + bin_lo) * g.SB;   // first entry of these keys in the offsets table
-                                                                        // (one entry per QS ordering keys)
+                                                                        // (one entry per CG ordering keys)
     int p0, r0, r1;
     sort2_range(hscan, l1, nblocks, part, p0, r0, r1);
-    const int *table = hist2 + (int64_t)l1 * kSort2Parts * g.l1bins * g.SB * g.QS;
-    const int kstride = g.l1bins * g.SB * g.QS;
-    // exclusive scan over the keys of (total over the parts) by one wave; cursor = p0 + keys before + parts before
+    const int *table = hist2 + (int64_t)l1 * kSort2Parts * g.l1bins * g.SB * g.CG;
+    const int kstride = g.l1bins * g.SB * g.CG;
+    // cursor of a key = p0 + keys before (totals over the parts) + the same key in the parts before this one.
+    // All threads fetch the counts (one round of loads), one wave scans the totals out of LDS.
+    int *const tot_lds = lds2 + kstride;
+    for (int idx = threadIdx.x; idx < nt0; idx += kSortThreads) {
+        int tot = 0, before = 0;
+#pragma unroll
+        for (int q = 0; q < kSort2Parts; ++q) {
+            const int c = table[q * kstride + idx];
+            tot += c;
+            before += q < part ? c : 0;
+        }
+        tot_lds[idx] = tot;
+        lds2[idx] = before;
+    }
+    __syncthreads();
     if (threadIdx.x < 64) {
         int carry = 0;
         for (int base = 0; base < nt0; base += 64) {
             const int idx = base + threadIdx.x;
-            int tot = 0, before = 0;
-            if (idx < nt0) {
-#pragma unroll
-                for (int q = 0; q < kSort2Parts; ++q) {
-                    const int c = table[q * kstride + idx];
-                    tot += c;
-                    before += q < part ? c : 0;
-                }
-            }
+            const int tot = idx < nt0 ? tot_lds[idx] : 0;
             int incl = tot;
             for (int off = 1; off < 64; off <<= 1) {
                 const int t = __shfl_up(incl, off);
@@ -313,12 +320,16 @@ sort2_scatter_kernel(Geom g, int npencils, int nblocks, const int *__restrict__ 
             }
             if (idx < nt0) {
                 const int excl = carry + incl - tot;
-                lds2[idx] = p0 + excl + before;
-                if (part == 0 && idx % g.QS == 0) offsets[obase + idx / g.QS] = p0 + excl;
+                lds2[idx] += p0 + excl;
+                if (part == 0) {
+                    const int bin = idx / g.CG, grp = idx - bin * g.CG;
+                    if (grp == 0) offsets[obase + bin] = p0 + excl;
+                    else groups[(obase + bin) * 2 + grp - 1] = p0 + excl;
+                }
             }
             carry += __shfl(incl, 63);
         }
-        if (part == 0 && l1 == npencils - 1 && threadIdx.x == 0) offsets[obase + nt0 / g.QS] = p0 + carry;  // = entries
+        if (part == 0 && l1 == npencils - 1 && threadIdx.x == 0) offsets[obase + nt0 / g.CG] = p0 + carry;  // = entries
     }
     __syncthreads();
     for (int j0 = r0 + threadIdx.x; j0 < r1; j0 += kSortThreads * 8) {
@@ -461,11 +472,11 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
         hipLaunchKernelGGL(sort1_scatter_kernel, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
                            npencils, nblocks, hscan, tmp);
         int *hist2 = (int *)(base + L.off_hist2);
-        const size_t lds2 = (size_t)g.l1bins * g.SB * g.QS * 4;
+        const size_t lds2 = (size_t)g.l1bins * g.SB * g.CG * 4;
         hipLaunchKernelGGL(sort2_count_kernel, dim3(npencils, kSort2Parts), dim3(kSortThreads), lds2, stream, g, nblocks,
                            hscan, tmp, hist2);
-        hipLaunchKernelGGL(sort2_scatter_kernel, dim3(npencils, kSort2Parts), dim3(kSortThreads), lds2, stream, g, npencils,
-                           nblocks, hscan, tmp, hist2, offsets, perm, spos);
+        hipLaunchKernelGGL(sort2_scatter_kernel, dim3(npencils, kSort2Parts), dim3(kSortThreads), 2 * lds2, stream, g,
+                           npencils, nblocks, hscan, tmp, hist2, offsets, (int *)(base + L.off_groups), perm, spos);
         if (g.wide) {
             // the record area is free now: it holds the overflow list of the load-balance split
             NFFT_HIP_CHECK(hipMemsetAsync(tmp, 0, 16, stream));

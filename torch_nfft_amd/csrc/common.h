@@ -86,15 +86,17 @@ struct Geom {
     // plan is sorted down to (tile, sub-block), so a tile's points are contiguous AND grouped by sub-block.
     // tile_offsets has one entry per (tile, sub-block): index tile * SB + s1 * sb2 + s2.
     int sb1, sb2, SB;
-    // Ordering-only sub-key of the second-level sort (no entry in tile_offsets; opt-in, NFFT_HIP_COLORDER=1): the
-    // points of a slab of a wide pencil are ordered by column quarter, so that a block of 32 consecutive points touches few 16-column groups of the
-    // padded tile and the gather kernels can skip the MFMA k-steps whose B fragments are all zero.
-    int QS;
+    // Column groups of the wide tiling (CG = 3, else 1): inside a slab the plan orders the points of a pencil by the
+    // group of their window in the padded 64-column tile -- 0: inside columns [0, 32), 1: inside [16, 48), 2: inside
+    // [32, 64) -- and records where groups 1 and 2 start (PlanLayout::off_groups, two ints per plan bin).  A K-block
+    // or gather block of one group needs two of the tile's four 16-column k-steps / one of its two 32-column halves:
+    // the matrix-core kernels skip the rest.  tile_offsets keeps one entry per slab.
+    int CG;
     int64_t cells; // M^dim
 };
 
 inline bool owned_supported(int dim, int64_t N, int64_t m);
-bool column_order_enabled();  // api.hip: NFFT_HIP_COLORDER=1 turns the column ordering inside slabs on
+bool column_groups_enabled();  // api.hip: NFFT_HIP_COLGROUPS=0 turns the column-group order of the plan off
 
 inline Geom make_geom(int dim, int64_t N, int64_t m, bool owned = false)
 {
@@ -136,7 +138,7 @@ inline Geom make_geom(int dim, int64_t N, int64_t m, bool owned = false)
     g.sb1 = sub ? g.Ta[1] / kSub : 1;
     g.sb2 = sub ? g.Ta[2] / kSub : 1;
     g.SB = g.sb1 * g.sb2;
-    g.QS = (g.wide && !g.owned && g.SB == 1 && column_order_enabled()) ? 4 : 1;
+    g.CG = (g.wide && !g.owned && g.SB == 1 && column_groups_enabled()) ? 3 : 1;
     return g;
 }
 
@@ -246,6 +248,10 @@ __device__ __forceinline__ void chunk_range(const Geom &g, const int *__restrict
     e = tile_offsets[(first_bin + hi) * g.SB];
 }
 
+// Column group of a point of the wide tiling whose cell lies `col` columns into its pencil (window = padded columns
+// [col, col + W), W <= 16): 0 if it ends by column 32, 2 if it starts at 32 or later, else 1 (then inside [16, 48)).
+__device__ __forceinline__ int column_group(const int col, const int W) { return col + W <= 32 ? 0 : (col >= 32 ? 2 : 1); }
+
 // Sub-block of a point inside its tile: s1 * sb2 + s2 (0 when the tile is not subdivided).
 __device__ __forceinline__ int sub_of_cells(const Geom &g, const int cell[3])
 {
@@ -299,6 +305,8 @@ struct PlanLayout {
     bool two_level;
     int64_t off_offsets, off_cursor, off_perm, off_spos, off_scan, scan_bytes;
     int64_t off_hist, off_hscan, off_tmp, off_hist2;
+    int64_t off_groups;  // column-group starts (two ints per plan bin) when `grouped`
+    bool grouped;        // the plan is ordered by column group inside the slabs (Geom::CG == 3, two-level sort)
     int64_t total;
 };
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }

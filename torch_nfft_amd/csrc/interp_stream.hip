@@ -2,21 +2,25 @@
 // consumer waves take blocks of points from a queue -- no workgroup barrier inside a work item.
 //
 // Same arithmetic as interp_mfma.hip (reference: csrc/cuda/spatial_window_operations.cu:214-332): per plane z of a
-// pencil and block of 32 points  T_z = G_z Psi2  (12 MFMAs on f16-split operands), t = sum_u1 psi1[u1] T_z[u1, i],
+// pencil and block of 32 points  T_z = G_z Psi2  (MFMAs on f16-split operands), t = sum_u1 psi1[u1] T_z[u1, i],
 // y_i += psi0_i[z] t.  What changes is the schedule.  interp_mfma.hip advances in lock step: stage the planes of a
 // chunk (all waves wait for the loads), barrier, every wave takes one block, barrier ... -- measured at config C3:
-// staging alone 0.44 ms, compute alone 1.30 ms, nothing overlaps, and a chunk's ~19 blocks leave 3 for a second round
-// (profiles/r02_experiments.md).  Here
-//   * 3 producer waves stage planes continuously: wave p takes the ring slots s = p (mod 3), i.e. the planes z with
-//     (z & 15) % 3 == p, of the item's
-//     sweep, loads the padded 32 x 64 tile (the next plane's loads are in flight while the current one is converted),
+// staging alone 0.44 ms, compute alone 1.30 ms, nothing overlaps (profiles/r02_experiments.md).  Here
+//   * 4 producer waves stage planes continuously: wave p takes the ring slots s = p (mod 4) of the item's sweep,
+//     loads the padded 32 x 64 tile (the next plane's loads are in flight while the current one is converted),
 //     scales it by its own power of two, f16-splits it into the ring slot z & 15 and publishes ready[slot] = z;
-//   * 13 consumer waves pull blocks from an LDS counter.  A block belongs to one chunk of 17 - (2m+2) slabs, so its
-//     window is at most the 16 planes of the ring; it publishes the first plane it needs (progress[wave]), builds
-//     its B fragments / psi1 weights, then walks its planes, waiting for each plane's ready flag;
+//   * 12 consumer waves pull blocks from an LDS counter.  A block is 32 points of ONE chunk (17 - (2m+2) slabs, so its
+//     window is at most the 16 planes of the ring) and, when the plan is ordered by column group (common.h), of ONE
+//     group: its windows then lie inside two of the tile's four 16-column k-steps, which halves the MFMAs, the B
+//     fragments and the A-fragment reads (measured: 1.43 -> 1.05 ms at C3 for half the k-steps).  The points of a
+//     (chunk, group) are the group's runs of the chunk's slabs, concatenated; blocks are handed out in the order of the
+//     run their first point lies in, i.e. by first slab, whatever the group -- so a wave's first plane never moves
+//     backwards.  A wave publishes that plane (progress[wave]), waits until all planes of the block are staged (one
+//     poll reads all 16 flags), builds its B fragments / psi1 weights and walks the planes without further checks; the
+//     A fragments of the next plane are requested as soon as the MFMAs that read a buffer are issued;
+//   * a wave claims its next block and fetches that block's points while it works on the current one;
 //   * a producer may overwrite slot z & 15 once every consumer's progress is beyond z - 16.  The slowest consumer
 //     needs planes below progress + 16 only, so the producers can always serve it: no cycle of waits.
-// Waves drift apart on their own, so the fragment builds (VALU) of some waves overlap the MFMAs of others.
 // Every spin loop is bounded (kSpinLimit): a logic error ends the kernel with wrong numbers, never a hung GPU.
 #include <algorithm>
 #include <climits>
@@ -32,10 +36,11 @@ namespace {
 
 constexpr int kIsThreads = 1024;
 constexpr int kIsWaves = kIsThreads / 64;
-constexpr int kIsProducers = 3;      // measured at C3: 1 producer 2.29 ms, 2: 1.58, 3: 1.43, 4: 1.47 (interp_mfma.hip: 1.63)
+constexpr int kIsProducers = 4;      // measured at C3: 3 producers 1.50 ms, 4: 1.41, 5: 1.50 (each owns 16 / 4 ring slots)
 constexpr int kIsConsumers = kIsWaves - kIsProducers;
 constexpr int kIsRing = 16;          // resident planes: TC + 2m+1 = 16 for every cutoff of the wide tiling
-constexpr int kIsMaxChunks = 64;     // chunks of one work item: one lane of the set-up wave each (<= 128 slabs / TC + 1)
+constexpr int kIsMaxSlabs = 160;     // slabs the chunks of one work item cover (<= 128 + 2 TC)
+constexpr int kIsMaxRuns = 3 * kIsMaxSlabs;
 constexpr int kSpinLimit = 1 << 22;
 
 struct __align__(16) StreamLds {
@@ -45,9 +50,10 @@ struct __align__(16) StreamLds {
     int progress[kIsConsumers];      // first plane a consumer still needs
     int next_block;                  // block queue (counts in units of 64: every lane adds 1)
     int abort;                       // set when a spin loop ran out: everybody leaves
-    int nchunks;
-    int chunk_blk[kIsMaxChunks + 1]; // blocks before chunk c of the item (prefix sums)
-    int chunk_pt[kIsMaxChunks + 1];  // first point of chunk c
+    // runs of the item: run e = (slab - first slab) * NG + group
+    int run_start[kIsMaxRuns + 4];   // first point of run e; [runs] = end of the last one
+    int run_cum[kIsMaxRuns + 4];     // points of the same chunk and group in front of run e
+    int run_blk[kIsMaxRuns + 4];     // blocks whose first point lies in a run before e (prefix sums); [runs] = all blocks
 };
 
 __device__ __forceinline__ int lds_load(const int *p)
@@ -59,16 +65,19 @@ __device__ __forceinline__ void lds_store(int *p, int v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int W, bool OVERFLOW>
+// NG: column groups of the plan (3, or 1 for plans without the group order: every block then spans all four k-steps)
+template <int W, bool OVERFLOW, int NG>
 __global__ void __launch_bounds__(kIsThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
-interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__restrict__ perm,
-                     const float *__restrict__ spos, const float *__restrict__ grid, const int Cr, const int plane0,
-                     float *__restrict__ yr, const int seg_slabs, const int nsegm, const int *__restrict__ first_end,
-                     const int4 *__restrict__ overflow)
+interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__restrict__ group_starts,
+                     const int *__restrict__ perm, const float *__restrict__ spos, const float *__restrict__ grid,
+                     const int Cr, const int plane0, float *__restrict__ yr, const int seg_slabs, const int nsegm,
+                     const int *__restrict__ first_end, const int4 *__restrict__ overflow)
 {
     constexpr int m = W / 2 - 1;
     constexpr int TC = 17 - W;
+    constexpr int NKS = NG == 3 ? 2 : 4;  // k-steps of a block
     static_assert(TC >= 1 && TC + W - 1 == kIsRing, "ring holds exactly one chunk's planes");
+    static_assert(128 + 2 * TC <= kIsMaxSlabs, "run tables");
     extern __shared__ __align__(16) unsigned char smem_raw[];
     StreamLds &L = *reinterpret_cast<StreamLds *>(smem_raw);
 
@@ -104,13 +113,10 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
     const int k_end = min(g.nta[0], (se + TC - 1) / TC);
     if (k_begin >= k_end) continue;
     const int bin0 = b * g.tiles_per_batch + pencil * g.np0;
-    const int nchunks = k_end - k_begin;  // <= kIsMaxChunks (launcher)
-    {
-        int s0, e0, s1, e1;
-        chunk_range(g, tile_offsets, bin0, k_begin, s0, e0);
-        chunk_range(g, tile_offsets, bin0, k_end - 1, s1, e1);
-        if (s0 == e1) continue;  // no points in these chunks
-    }
+    const int s0 = k_begin * TC;                    // first slab of the item's chunks
+    const int nsl = min(k_end * TC, M) - s0;        // slabs they cover (<= kIsMaxSlabs: a range holds <= 128 slabs)
+    const int nruns = nsl * NG;
+    if (tile_offsets[bin0 + s0] == tile_offsets[bin0 + s0 + nsl]) continue;  // no points in these chunks
     const int j2 = pencil % g.nta[2], j1 = pencil / g.nta[2];
     const int tb1 = j1 * g.Ta[1], tb2 = j2 * g.Ta[2];
     const float sc = win_exp_scale(m);
@@ -118,32 +124,46 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
     norm = norm * norm * norm;
     const float *const gplane = grid + (int64_t)plane_local * g.cells;
 
-    // ---- item set-up: chunk table, flags ----------------------------------------------------------------------
+    // ---- item set-up: run tables, flags -----------------------------------------------------------------------
     __syncthreads();  // the previous item is done with the LDS
+    for (int e = tid; e <= nruns; e += kIsThreads) {
+        const int s = e / NG, q = e - s * NG;
+        const int bin = bin0 + s0 + s;
+        L.run_start[e] = q == 0 ? tile_offsets[bin] : group_starts[2 * (int64_t)bin + q - 1];
+    }
     if (wave == 0) {
-        // blocks per chunk -> prefix sums (nchunks <= 64: one lane per chunk)
-        int s = 0, e = 0;
-        if (lane < nchunks) chunk_range(g, tile_offsets, bin0, k_begin + lane, s, e);
-        const int nb = (e - s + 31) >> 5;
-        int incl = nb;
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
-        }
-        if (lane < nchunks) {
-            L.chunk_blk[lane] = incl - nb;
-            L.chunk_pt[lane] = s;
-        }
-        if (lane == nchunks - 1) {
-            L.chunk_blk[nchunks] = incl;
-            L.chunk_pt[nchunks] = e;
-        }
         if (lane < kIsRing) L.ready[lane] = INT_MIN;
-        if (lane < kIsConsumers) L.progress[lane] = k_begin * TC - m;
-        if (lane == 0) { L.next_block = 0; L.abort = 0; L.nchunks = nchunks; }
+        if (lane < kIsConsumers) L.progress[lane] = s0 - m;
+        if (lane == 0) { L.next_block = 0; L.abort = 0; }
     }
     __syncthreads();
-    const int total_blocks = L.chunk_blk[nchunks];
+    for (int e = tid; e < nruns; e += kIsThreads) {
+        // blocks of a (chunk, group) are cut from the concatenation of the group's runs over the chunk's slabs
+        const int s = e / NG;
+        const int t = s % TC;
+        int cum = 0;
+        for (int k = 1; k <= t; ++k) cum += L.run_start[e - k * NG + 1] - L.run_start[e - k * NG];
+        const int len = L.run_start[e + 1] - L.run_start[e];
+        L.run_cum[e] = cum;
+        L.run_blk[e] = ((cum + len + 31) >> 5) - ((cum + 31) >> 5);  // blocks whose first point lies in this run
+    }
+    __syncthreads();
+    if (wave == 0) {
+        int carry = 0;
+        for (int base = 0; base <= nruns; base += 64) {
+            const int e = base + lane;
+            const int nb = e < nruns ? L.run_blk[e] : 0;
+            int incl = nb;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off);
+                if (lane >= off) incl += t;
+            }
+            if (e <= nruns) L.run_blk[e] = carry + incl - nb;
+            carry += __shfl(incl, 63);
+        }
+    }
+    __syncthreads();
+    const int total_blocks = L.run_blk[nruns];
 
     if (wave >= kIsConsumers) {
         // ================================ producer: planes z = z_begin + p, + 4, ... ================================
@@ -156,8 +176,8 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
             const int k_hi = min(k_end - 1, (z + m) / TC), k_lo = max(k_begin, (z - TC - m + TC - 1) / TC);
             for (int k = k_lo; k <= k_hi; ++k) {
                 if (k < k_begin) continue;
-                const int c = k - k_begin;
-                if (L.chunk_blk[c + 1] > L.chunk_blk[c]) return true;
+                const int lo = (k - k_begin) * TC, hi = min(lo + TC, nsl);
+                if (L.run_start[hi * NG] > L.run_start[lo * NG]) return true;
             }
             return false;
         };
@@ -253,37 +273,79 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
         }
     } else {
         // ================================ consumer: blocks from the queue ===========================================
-        int chunk = 0;  // chunks only move forward for a wave
-        while (true) {
+        // A wave claims its next block while it still works on the current one and fetches that block's points (sorted
+        // position, output index) early.  Near the end of the queue blocks are claimed only when the wave is ready
+        // for them, so that no wave sits on a block while others run dry.
+        int run = 0;  // run of the last claimed block's first point: only moves forward
+        auto claim = [&]() {
             // all 64 lanes add 1 (one ds_add of 64 per wave): the counter runs in units of 64
-            const int blk = __builtin_amdgcn_readfirstlane(atomicAdd(&L.next_block, 1)) >> 6;
-            if (blk >= total_blocks || lds_load(&L.abort)) break;
-            while (L.chunk_blk[chunk + 1] <= blk) ++chunk;
-            const int s = L.chunk_pt[chunk], e = L.chunk_pt[chunk + 1];
-            const int j0 = s + (blk - L.chunk_blk[chunk]) * 32;
-            const int j = j0 + r32;
-            const bool valid = j < e;
+            return __builtin_amdgcn_readfirstlane(atomicAdd(&L.next_block, 1)) >> 6;
+        };
+        // my point of block `blk` (index into the plan, -1: none), the block's group
+        auto fetch = [&](const int blk, int &idx, int &grp, float &a0, float &a1, float &a2, int &pm) {
+            while (L.run_blk[run + 1] <= blk) ++run;
+            const int s = run / NG;
+            grp = run - s * NG;
+            const int t = s % TC;
+            const int cum = L.run_cum[run];
+            // position of the block's first point inside its run, then mine: walk the group's runs of the chunk
+            int x = 32 * (((cum + 31) >> 5) + blk - L.run_blk[run]) - cum + r32;
+            idx = -1;
+#pragma unroll
+            for (int k = 0; k < TC; ++k) {
+                if (t + k < TC && s + k < nsl) {  // wave-uniform
+                    const int e = run + k * NG;
+                    const int st = L.run_start[e], len = L.run_start[e + 1] - st;
+                    if (idx < 0 && x >= 0) {
+                        if (x < len) idx = st + x;
+                        x -= len;  // (negative once found)
+                    }
+                }
+            }
+            a0 = a1 = a2 = 0.0f;
+            pm = 0;
+            if (idx >= 0) {
+                a0 = spos[(int64_t)idx * 3 + 0];
+                a1 = spos[(int64_t)idx * 3 + 1];
+                a2 = spos[(int64_t)idx * 3 + 2];
+                pm = perm[idx];
+            }
+        };
+        int blk = claim();
+        int idx = -1, grp = 0, pj = 0;
+        float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f;
+        if (blk < total_blocks) fetch(blk, idx, grp, q0, q1, q2, pj);
+        while (blk < total_blocks && !lds_load(&L.abort)) {
+            const bool ahead = blk + 2 * kIsConsumers <= total_blocks;
+            int nblk = total_blocks, nidx = -1, ngrp = 0, npj = 0;
+            float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
+            if (ahead) {
+                nblk = claim();
+                if (nblk < total_blocks) fetch(nblk, nidx, ngrp, n0, n1, n2, npj);
+            }
+            const bool valid = idx >= 0;
             int c0 = 0, c1 = 0, c2 = 0;
             float f0 = 0.f, f1 = 0.f, f2 = 0.f;
             if (valid) {
-                split_cell(spos[(int64_t)j * 3 + 0], M, c0, f0);
-                split_cell(spos[(int64_t)j * 3 + 1], M, c1, f1);
-                split_cell(spos[(int64_t)j * 3 + 2], M, c2, f2);
+                split_cell(q0, M, c0, f0);
+                split_cell(q1, M, c1, f1);
+                split_cell(q2, M, c2, f2);
             }
-            // the plan is sorted by slab: the block's planes run from the first point's window to the last one's
-            const int nvalid = min(32, e - j0);
+            // the points of a block are ordered by slab: its planes run from the first point's window to the last one's
+            const int nvalid = __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && h == 0));
             const int z_first = __builtin_amdgcn_readlane(c0, 0) - m;
             const int z_last = __builtin_amdgcn_readlane(c0, nvalid - 1) + m + 1;
             if (lane == 0) lds_store(&L.progress[wave], z_first);  // planes below are no longer mine
+            const int ks0 = NG == 3 ? grp : 0;  // first k-step of the block's group
 
-            // B fragments: psi2 of my point on the padded columns 16 ks + 8 h + jj (zero outside the window).
+            // B fragments: psi2 of my point on the padded columns 16 (ks0 + ks) + 8 h + jj (zero outside the window).
             // d = f2 + m - l2 with l2 = column - o2: one subtraction from a per-lane base per value; the scale 2^11 of
             // the operand rides in the exponent; padding lanes get a base far outside every window.
-            u32x4 bh[4], bl[4];
-            const int o2h = c2 - tb2 - 8 * h;  // padded column of tap 0, minus this lane's column offset
+            u32x4 bh[NKS], bl[NKS];
+            const int o2h = c2 - tb2 - 8 * h - 16 * ks0;  // padded column of tap 0, minus this lane's column offset
             const float dbase2 = valid ? f2 + (float)(m + o2h) : 1.0e4f;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < NKS; ++ks) {
                 float w[8];
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
@@ -291,20 +353,14 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
                     const float ev = __builtin_amdgcn_exp2f(fmaf(d * d, sc, 11.0f));  // exp2(sc d^2) * kOpScale
                     w[jj] = (unsigned)(16 * ks + jj - o2h) < (unsigned)W ? ev : 0.0f;
                 }
-                unsigned h0, h1, h2, h3, q0, q1, q2, q3;
-                split_pair(w[0], w[1], h0, q0);
-                split_pair(w[2], w[3], h1, q1);
-                split_pair(w[4], w[5], h2, q2);
-                split_pair(w[6], w[7], h3, q3);
+                unsigned h0, h1, h2, h3, p0, p1, p2, p3;
+                split_pair(w[0], w[1], h0, p0);
+                split_pair(w[2], w[3], h1, p1);
+                split_pair(w[4], w[5], h2, p2);
+                split_pair(w[6], w[7], h3, p3);
                 bh[ks] = u32x4{h0, h1, h2, h3};
-                bl[ks] = u32x4{q0, q1, q2, q3};
+                bl[ks] = u32x4{p0, p1, p2, p3};
             }
-            // 16-column groups of the padded tile that no point of the block touches: their B fragments are all zero and
-            // the k-step is skipped (the plan orders the points of a slab by column quarter: ~2.5 of 4 groups are live)
-            bool live[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                live[ks] = __builtin_amdgcn_ballot_w64((bh[ks].x | bh[ks].y | bh[ks].z | bh[ks].w) != 0u) != 0ull;
             // psi1 of my point on the 16 rows this lane holds of every T_z (MFMA result layout): row = r + 8 q + 4 h
             float w1[16];
             const int o1h = c1 - tb1 - 4 * h;
@@ -319,38 +375,82 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
 
             float y = 0.0f;
             bool bail = false;
-            for (int z = z_first; z <= z_last; ++z) {
-                const int slot = z & (kIsRing - 1);
+            // All planes of the block first (one poll reads the 16 flags: lane s looks at slot s), then a loop without
+            // flag round trips.  One A-fragment buffer per k-step: as soon as the MFMAs of (z, ks) are issued the
+            // fragments of (z + 1, ks) are requested into the same registers -- the other k-steps' MFMAs and the
+            // reduction cover the LDS latency, which under this load is several hundred cycles.
+            {
+                const int zs = z_first + ((lane - z_first) & (kIsRing - 1));  // the plane of my window that lives in slot `lane`
+                const bool need = lane < kIsRing && zs <= z_last;
                 int spins = 0;
-                while (lds_load(&L.ready[slot]) != z) {
+                while (true) {
+                    const int v = need ? lds_load(&L.ready[lane]) : zs;
+                    if (__builtin_amdgcn_ballot_w64(v != zs) == 0ull) break;
                     if (lds_load(&L.abort) || ++spins > kSpinLimit) { bail = true; break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
-                if (bail) break;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                f32x16 acc = 0.0f;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    if (!live[ks]) continue;  // wave-uniform
-                    const f16x8 ah = L.frag[slot][ks][0][lane], al = L.frag[slot][ks][1][lane];
-                    const f16x8 bhk = __builtin_bit_cast(f16x8, bh[ks]), blk2 = __builtin_bit_cast(f16x8, bl[ks]);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhk, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blk2, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhk, acc, 0, 0, 0);
-                }
-                float t = 0.0f;
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) t = fmaf(w1[reg], acc[reg], t);
-                // axis-0 weight of plane z for my point (zero outside its window), times the plane's scale
-                const int l0 = z - (c0 - m);
-                const float d0 = f0 + (float)(m - l0);
-                float p0 = __builtin_amdgcn_exp2f(sc * d0 * d0) * L.pinv[slot];
-                p0 = (unsigned)l0 < (unsigned)W ? p0 : 0.0f;
-                y = fmaf(p0, t, y);
             }
             if (bail) { lds_store(&L.abort, 1); break; }
+            {
+                f16x8 A[NKS][2];
+                const float pinv_first = L.pinv[z_first & (kIsRing - 1)];
+                {
+                    // same request order as in the loop (the compiler's wait counts merge both paths into the loop head)
+                    const int slot = z_first & (kIsRing - 1);
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        A[ks][0] = L.frag[slot][ks0 + ks][0][lane];
+                        A[ks][1] = L.frag[slot][ks0 + ks][1][lane];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                auto plane_weight = [&](const int z, const float pinv) {
+                    // axis-0 weight of plane z for my point (zero outside its window), times the plane's scale
+                    const int l0 = z - (c0 - m);
+                    const float d0 = f0 + (float)(m - l0);
+                    const float p0 = __builtin_amdgcn_exp2f(sc * d0 * d0) * pinv;
+                    return (unsigned)l0 < (unsigned)W ? p0 : 0.0f;
+                };
+                float pw = plane_weight(z_first, pinv_first);
+                for (int z = z_first; z <= z_last; ++z) {
+                    const int nz = min(z + 1, z_last);  // (the last plane re-reads itself: no branch in the loop body)
+                    const int nslot = nz & (kIsRing - 1);
+                    // requested before the fragments: LDS answers in order, waiting for it must not wait for them
+                    const float pinv_next = L.pinv[nslot];
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x16 acc = 0.0f;
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        const f16x8 bhk = __builtin_bit_cast(f16x8, bh[ks]), blk2 = __builtin_bit_cast(f16x8, bl[ks]);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[ks][0], bhk, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[ks][0], blk2, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[ks][1], bhk, acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        A[ks][0] = L.frag[nslot][ks0 + ks][0][lane];
+                        A[ks][1] = L.frag[nslot][ks0 + ks][1][lane];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const float pw_next = plane_weight(nz, pinv_next);
+                    float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+                    for (int reg = 0; reg < 16; reg += 2) {
+                        t0 = fmaf(w1[reg], acc[reg], t0);
+                        t1 = fmaf(w1[reg + 1], acc[reg + 1], t1);
+                    }
+                    y = fmaf(pw, t0 + t1, y);
+                    pw = pw_next;
+                }
+            }
             y += __shfl_xor(y, 32);  // the two row halves of the point
-            if (valid && h == 0) yr[(int64_t)perm[j] * Cr + cr] = y * norm;
+            if (valid && h == 0) yr[(int64_t)pj * Cr + cr] = y * norm;
+            if (!ahead) {
+                nblk = claim();
+                if (nblk < total_blocks) fetch(nblk, nidx, ngrp, n0, n1, n2, npj);
+            }
+            blk = nblk; idx = nidx; grp = ngrp; pj = npj;
+            q0 = n0; q1 = n1; q2 = n2;
         }
         // nothing of the ring is mine any more: the producers may run to the end of their sweep
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -362,8 +462,8 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
 } // namespace
 
 // Worth it when the work items are big: the pipeline's warm-up and tail cost ~10 us per item.  The size of an item in
-// a populated region is the plan's target (seg_target_points: n / (5.4 CUs), at least 2048 points): 7 237 at config C3
-// (1.63 -> 1.43 ms), 2 048 at C5, where the lock-step kernel stays ahead (0.62 vs 0.69 ms).
+// a populated region is the plan's target (seg_target_points: n / (5.4 CUs), at least 2048 points): 7 237 at config C3,
+// 2 048 at C5, where the lock-step kernel stays ahead (0.62 vs 0.69 ms).
 bool interp_stream_pays(const Geom &g, const PlanLayout &L, int64_t n)
 {
     int64_t nsets = g.tiles_per_batch > 0 ? L.ntiles / g.tiles_per_batch : 1;
@@ -377,17 +477,16 @@ bool interp_stream_supported(const Geom &g)
         const char *env = std::getenv("NFFT_HIP_GATHER");
         return env && (env[0] == 'l' || env[0] == 'm');  // lds: lane-per-point kernel, mfma: plane-ring kernel in lock step
     }();
-    // chunk table: a work item has at most ceil(128 / TC) + 1 chunks
-    const int TC = 17 - g.W;
-    return !off && g.dim == 3 && g.wide && !g.owned && TC >= 1 && (128 + TC - 1) / TC + 1 <= kIsMaxChunks;
+    return !off && g.dim == 3 && g.wide && !g.owned && g.W <= 16;
 }
 
-template <int W>
+template <int W, int NG>
 static int launch_is_t(const Geom &g, const PlanLayout &L, const void *plan, const float *grid, int64_t n, int64_t Cr,
                        int64_t plane0, int64_t nplanes, float *yr, hipStream_t stream)
 {
     const char *base = (const char *)plan;
     const int *to = (const int *)(base + L.off_offsets);
+    const int *gs = (const int *)(base + L.off_groups);
     const int *perm = (const int *)(base + L.off_perm);
     const float *spos = (const float *)(base + L.off_spos);
     const int *first_end = (const int *)(base + L.off_cursor);
@@ -399,22 +498,30 @@ static int launch_is_t(const Geom &g, const PlanLayout &L, const void *plan, con
     const dim3 blocks((unsigned)(pencils * nsegm), (unsigned)nplanes);
     static DeviceOnce attr_done;
     if (attr_done.first_use()) {
-        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)interp_stream_kernel<W, false>,
+        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)interp_stream_kernel<W, false, NG>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(StreamLds)));
-        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)interp_stream_kernel<W, true>,
+        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)interp_stream_kernel<W, true, NG>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(StreamLds)));
         attr_done.mark();
     }
-    hipLaunchKernelGGL((interp_stream_kernel<W, false>), blocks, dim3(kIsThreads), sizeof(StreamLds), stream, g, to, perm,
-                       spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, (const int4 *)nullptr);
+    hipLaunchKernelGGL((interp_stream_kernel<W, false, NG>), blocks, dim3(kIsThreads), sizeof(StreamLds), stream, g, to, gs,
+                       perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, (const int4 *)nullptr);
     if (L.two_level) {
         const int4 *overflow = (const int4 *)(base + L.off_tmp);
         const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
-        hipLaunchKernelGGL((interp_stream_kernel<W, true>), oblocks, dim3(kIsThreads), sizeof(StreamLds), stream, g, to,
-                           perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, overflow);
+        hipLaunchKernelGGL((interp_stream_kernel<W, true, NG>), oblocks, dim3(kIsThreads), sizeof(StreamLds), stream, g, to,
+                           gs, perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, overflow);
     }
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+template <int W>
+static int launch_is_w(const Geom &g, const PlanLayout &L, const void *plan, const float *grid, int64_t n, int64_t Cr,
+                       int64_t plane0, int64_t nplanes, float *yr, hipStream_t stream)
+{
+    return L.grouped ? launch_is_t<W, 3>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream)
+                     : launch_is_t<W, 1>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
 }
 
 int launch_interp_stream(const Geom &g, const PlanLayout &L, const void *plan, const float *grid, int64_t n, int64_t Cr,
@@ -422,13 +529,13 @@ int launch_interp_stream(const Geom &g, const PlanLayout &L, const void *plan, c
 {
     if (nplanes <= 0 || n <= 0) return 0;
     switch (g.m) {
-    case 1: return launch_is_t<4>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
-    case 2: return launch_is_t<6>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
-    case 3: return launch_is_t<8>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
-    case 4: return launch_is_t<10>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
-    case 5: return launch_is_t<12>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
-    case 6: return launch_is_t<14>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
-    case 7: return launch_is_t<16>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 1: return launch_is_w<4>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 2: return launch_is_w<6>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 3: return launch_is_w<8>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 4: return launch_is_w<10>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 5: return launch_is_w<12>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 6: return launch_is_w<14>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 7: return launch_is_w<16>(g, L, plan, grid, n, Cr, plane0, nplanes, yr, stream);
     }
     set_error("matrix-core interpolation supports cutoff 1..7");
     return 1;

@@ -55,6 +55,7 @@ struct __align__(16) MfmaOps {
     float psi1[kNKB][32][kPsiStride];     // [K-block][row][point]
     float atab[kNKB][W][kKB];             // [K-block][axis-0 tap][point]   x' * psi0
     int slab[kNKB];
+    int halves[kNKB];                     // bit t: some tap of the K-block lies in column tile t (else its MFMAs are skipped)
 };
 
 // Points of one batch (cell fractions, in-pencil cells, scaled value), double-buffered as well.
@@ -358,6 +359,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                 O.bfrag[j][1][0][lane] = zero;
                 O.bfrag[j][1][1][lane] = zero;
                 asm volatile("" ::: "memory");  // the 16-bit scatter below must stay behind the zero fill
+                int touched = 0;
                 for (int e = lane; e < W * kKB; e += 64) {
                     const int k = e / W, l = e - k * W;
                     const int slot = j * kKB + k;
@@ -372,8 +374,13 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                         _Float16 *pl = (_Float16 *)&O.bfrag[j][col >> 5][1][ln];
                         ph[k & 7] = __builtin_bit_cast(_Float16, (unsigned short)hi);
                         pl[k & 7] = __builtin_bit_cast(_Float16, (unsigned short)lo);
+                        touched |= 1 + (col >> 5);
                     }
                 }
+                // the plan orders a slab's points by column group (common.h): most K-blocks touch one tile only
+                const int t0 = __builtin_amdgcn_ballot_w64((touched & 1) != 0) != 0ull;
+                const int t1 = __builtin_amdgcn_ballot_w64((touched & 2) != 0) != 0ull;
+                if (lane == 0) O.halves[j] = t0 + 2 * t1;
             } else if (kind == 1) {
                 // psi1 table [row][point]
                 f32x4 *pz = (f32x4 *)&O.psi1[j][0][0];
@@ -407,8 +414,10 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     // ---- every wave adds the K-blocks that reach its plane -------------------------------------------------
     auto accumulate = [&](const MfmaOps<W> &O, const int nkb) {
         const int slabs = O.slab[lane & (kNKB - 1)];  // one LDS read; K-block j's slab by readlane
+        const int halves = O.halves[lane & (kNKB - 1)];
         for (int j = 0; j < nkb; ++j) {
             const int s = __builtin_amdgcn_readlane(slabs, j);
+            const int hv = __builtin_amdgcn_readlane(halves, j);
             // the sweep has passed plane myz once the current slab is beyond myz + m
             while (myz + m < s) {
                 flush();
@@ -426,23 +435,32 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                 split_product_pair(p1.z, a1.z, p1.w, a1.w, h3, q3);
                 const u32x4 uh = {h0, h1, h2, h3}, ul = {q0, q1, q2, q3};
                 const f16x8 ah = __builtin_bit_cast(f16x8, uh), al = __builtin_bit_cast(f16x8, ul);
-                const f16x8 b0h = O.bfrag[j][0][0][lane], b0l = O.bfrag[j][0][1][lane];
-                const f16x8 b1h = O.bfrag[j][1][0][lane], b1l = O.bfrag[j][1][1][lane];
-                if constexpr (OWNED) {
-                    // transposed product (columns x rows): the fragments of the two operands have the same lane layout
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0h, ah, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1h, ah, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0l, ah, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1l, ah, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0h, al, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1h, al, acc1, 0, 0, 0);
-                } else {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0h, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1h, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0l, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1l, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b0h, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1h, acc1, 0, 0, 0);
+                // one column tile after the other (their B fragments are not live at the same time: the kernel sits at
+                // the register limit, and a spill here costs more than the interleaving of the two chains gains)
+                if (hv & 1) {
+                    const f16x8 b0h = O.bfrag[j][0][0][lane], b0l = O.bfrag[j][0][1][lane];
+                    if constexpr (OWNED) {
+                        // transposed product (columns x rows): the fragments of the two operands have the same lane layout
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0h, ah, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0l, ah, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0h, al, acc0, 0, 0, 0);
+                    } else {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0h, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0l, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b0h, acc0, 0, 0, 0);
+                    }
+                }
+                if (hv & 2) {
+                    const f16x8 b1h = O.bfrag[j][1][0][lane], b1l = O.bfrag[j][1][1][lane];
+                    if constexpr (OWNED) {
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1h, ah, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1l, ah, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1h, al, acc1, 0, 0, 0);
+                    } else {
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1h, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1l, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1h, acc1, 0, 0, 0);
+                    }
                 }
                 dirty = true;
             }
