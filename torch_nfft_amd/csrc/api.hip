@@ -135,10 +135,18 @@ struct PlanSet {
     const PlanLayout &spread_layout() const { return owned ? Lo : L; }
     const void *spread_plan(const void *plan) const { return owned ? (const char *)plan + off_own : (const char *)plan; }
 };
+// Geometry of a problem's (halo-tiling) plan.  The column-group order of the plan (common.h Geom::CG) pays where the
+// streamed gather runs, i.e. for big work items; below that it only costs sorting time (+0.03 ms at 10^6 points).
+Geom problem_geom(const nfft_hip_problem *p)
+{
+    Geom g = make_geom(p->dim, p->N, p->m);
+    if (g.CG > 1 && !stream_items(p->num_points, p->batch_size, device_cu_count())) g.CG = 1;
+    return g;
+}
 PlanSet plan_set(const nfft_hip_problem *p)
 {
     PlanSet ps;
-    ps.g = make_geom(p->dim, p->N, p->m);
+    ps.g = problem_geom(p);
     ps.L = plan_layout(ps.g, p->num_points, p->batch_size);
     ps.owned = choose_owned(p->dim, p->N, p->m, p->num_points, p->batch_size,
                             (p->flags & NFFT_HIP_POINTS_IN_QUARTER_BALL) ? 0.125 : 1.0);
@@ -224,14 +232,28 @@ struct Carve {
 
 bool spread_reg_enabled() { return subblock_plan_enabled(); }
 
-int spread_any(const Geom &g, const PlanLayout &L, const void *plan, const float *xs, int64_t n, int64_t Cr,
+// The matrix-core spreading kernel permutes one or two real coefficient columns itself (its pass over a work item's
+// points that finds their largest |x| reads the caller's row-major array through the plan's permutation and leaves
+// the plan-ordered copy in xs): no separate permutation pass, 0.18 ms at C3.  With more columns one pass
+// (gather_rows) reads every row once for all of them.  NFFT_HIP_XGATHER=1 always runs the separate pass.
+bool spread_permutes(const Geom &g, int64_t Cr)
+{
+    static const bool off = [] {
+        const char *env = std::getenv("NFFT_HIP_XGATHER");
+        return env && env[0] == '1';
+    }();
+    return !off && spread_mfma_supported(g) && Cr <= 2;
+}
+
+// xs: the planar copy in plan order; xr: nullptr when the caller has filled xs, else what spread_permutes() reads
+int spread_any(const Geom &g, const PlanLayout &L, const void *plan, const float *xr, float *xs, int64_t n, int64_t Cr,
                int64_t p0, int64_t np, float *grid, hipStream_t s)
 {
     if (spread_mfma_supported(g)) {
         // (the owner-computes variant writes every cell itself)
         if (!g.owned) { StageTimer t(kStageZero, s); NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(np * g.cells * 4), s)); }
         StageTimer t(kStageSpread, s);
-        return launch_spread_mfma(g, L, plan, xs, n, Cr, p0, np, grid, s);
+        return launch_spread_mfma(g, L, plan, xr, xs, n, Cr, p0, np, grid, s);
     }
     if (spread_reg_supported(g) && spread_reg_enabled()) {
         StageTimer t(kStageSpread, s);
@@ -387,15 +409,16 @@ int nfft_hip_spread(const nfft_hip_problem *p, const void *plan, const float *xr
     hipStream_t s = (hipStream_t)stream;
     const int64_t planes = p->batch_size * real_columns;
     if (planes > 32768) { set_error("Input mismatch: too many planes for one spread call"); return NFFT_HIP_EINVAL; }
+    if (spread_permutes(g, real_columns)) return spread_any(g, L, plan, xr, scratch, p->num_points, real_columns, 0, planes, grid, s);
     if (int rc = launch_gather_rows(g, L, plan, p->num_points, xr, real_columns, scratch, s)) return rc;
-    return spread_any(g, L, plan, scratch, p->num_points, real_columns, 0, planes, grid, s);
+    return spread_any(g, L, plan, nullptr, scratch, p->num_points, real_columns, 0, planes, grid, s);
 }
 
 int nfft_hip_interpolate(const nfft_hip_problem *p, const void *plan, const float *grid, int64_t real_columns,
                          float *yr, void *stream)
 {
     if (int rc = validate(p)) return rc;
-    const Geom g = make_geom(p->dim, p->N, p->m);
+    const Geom g = problem_geom(p);
     const PlanLayout L = plan_layout(g, p->num_points, p->batch_size);
     const int64_t planes = p->batch_size * real_columns;
     if (planes > 32768) { set_error("Input mismatch: too many planes for one interpolate call"); return NFFT_HIP_EINVAL; }
@@ -430,10 +453,11 @@ static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64
     const Geom &gs = c.ps.spread_geom();
     const PlanLayout &Ls = c.ps.spread_layout();
     const void *plan_s = c.ps.spread_plan(plan);
-    { StageTimer t(kStageGather, s); if (int rc = launch_gather_rows(gs, Ls, plan_s, c.n, (const float *)x, c.Cr, xs, s)) return rc; }
+    const bool fused = spread_permutes(gs, c.Cr);
+    if (!fused) { StageTimer t(kStageGather, s); if (int rc = launch_gather_rows(gs, Ls, plan_s, c.n, (const float *)x, c.Cr, xs, s)) return rc; }
     for (int64_t p0 = 0; p0 < c.total_planes; p0 += c.chunk_planes) {
         const int64_t np = std::min(c.chunk_planes, c.total_planes - p0);
-        if (int rc = spread_any(gs, Ls, plan_s, xs, c.n, c.Cr, p0, np, grid, s)) return rc;
+        if (int rc = spread_any(gs, Ls, plan_s, fused ? (const float *)x : nullptr, xs, c.n, c.Cr, p0, np, grid, s)) return rc;
         if (c.colfft) {
             const bool own_rows = own_row_passes(c.g);
             if (own_rows) { StageTimer t(kStageFft, s); if (int rc = launch_row_r2c(c.g, grid, ws + c.off_col, c.chunk_planes, np, spec, s)) return rc; }

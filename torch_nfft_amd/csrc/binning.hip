@@ -213,7 +213,7 @@ sort1_scatter_kernel(Geom g, const float *__restrict__ pos, const int64_t *__res
 }
 
 // (axis-0 bin, sub-block) key of a level-1 record inside its first-level bin (whose first axis-0 bin is bin_lo)
-__device__ __forceinline__ int fine_key(const Geom &g, const float4 rec, const int bin_lo)
+__device__ __forceinline__ int fine_key(const Geom &g, const float4 rec, const int bin_lo, const int col0)
 {
     if (g.dim != 3) return 0;
     int cell[3];
@@ -227,8 +227,9 @@ __device__ __forceinline__ int fine_key(const Geom &g, const float4 rec, const i
     }
     if (g.CG > 1) {
         // ordering inside the slab: column group of the point's window in the padded tile
+        // (col0 = first column of the pencil the record was binned into)
         split_cell(rec.z, g.M, cell[2], fr);
-        key = key * g.CG + column_group(cell[2] % g.Ta[2], g.W);
+        key = key * g.CG + column_group(cell[2] - col0, g.W);
     }
     return key;
 }
@@ -256,6 +257,7 @@ sort2_count_kernel(Geom g, int nblocks, const int *__restrict__ hscan, const flo
     const int l1 = blockIdx.x, part = blockIdx.y;
     const int pencil = l1 / g.l1seg, sg = l1 - pencil * g.l1seg;
     const int bin_lo = sg * g.l1bins;
+    const int col0 = (pencil % g.nta[2]) * g.Ta[2];
     const int nt0 = (min(g.np0, bin_lo + g.l1bins) - bin_lo) * g.SB * g.CG;  // fine keys of this first-level bin
     int p0, r0, r1;
     sort2_range(hscan, l1, nblocks, part, p0, r0, r1);
@@ -270,7 +272,7 @@ sort2_count_kernel(Geom g, int nblocks, const int *__restrict__ hscan, const flo
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-            if (j0 + q * kSortThreads < r1) atomicAdd(&lds2[fine_key(g, rec[q], bin_lo)], 1);
+            if (j0 + q * kSortThreads < r1) atomicAdd(&lds2[fine_key(g, rec[q], bin_lo, col0)], 1);
     }
     __syncthreads();
     int *out = hist2 + ((int64_t)l1 * kSort2Parts + part) * g.l1bins * g.SB * g.CG;
@@ -286,6 +288,7 @@ sort2_scatter_kernel(Geom g, int npencils, int nblocks, const int *__restrict__ 
     const int l1 = blockIdx.x, part = blockIdx.y;
     const int pencil = l1 / g.l1seg, sg = l1 - pencil * g.l1seg;
     const int bin_lo = sg * g.l1bins;
+    const int col0 = (pencil % g.nta[2]) * g.Ta[2];
     const int nt0 = (min(g.np0, bin_lo + g.l1bins) - bin_lo) * g.SB * g.CG;
     const int64_t obase = ((int64_t)pencil * g.np0 + bin_lo) * g.SB;   // first entry of these keys in the offsets table
                                                                         // (one entry per CG ordering keys)
@@ -343,7 +346,7 @@ sort2_scatter_kernel(Geom g, int npencils, int nblocks, const int *__restrict__ 
         for (int q = 0; q < 8; ++q) {
             if (j0 + q * kSortThreads >= r1) continue;
             const float4 rec = recs[q];
-            const int slot = atomicAdd(&lds2[fine_key(g, rec, bin_lo)], 1);
+            const int slot = atomicAdd(&lds2[fine_key(g, rec, bin_lo, col0)], 1);
             perm[slot] = __float_as_int(rec.w);
             spos[(int64_t)slot * g.dim] = rec.x;
             if (g.dim > 1) spos[(int64_t)slot * g.dim + 1] = rec.y;

@@ -36,7 +36,10 @@ namespace {
 
 constexpr int kIsThreads = 1024;
 constexpr int kIsWaves = kIsThreads / 64;
-constexpr int kIsProducers = 4;      // measured at C3: 3 producers 1.50 ms, 4: 1.41, 5: 1.50 (each owns 16 / 4 ring slots)
+#ifndef IS_PRODUCERS
+#define IS_PRODUCERS 4
+#endif
+constexpr int kIsProducers = IS_PRODUCERS;      // measured at C3: 3 producers 1.50 ms, 4: 1.41, 5: 1.50 (each owns 16 / 4 ring slots)
 constexpr int kIsConsumers = kIsWaves - kIsProducers;
 constexpr int kIsRing = 16;          // resident planes: TC + 2m+1 = 16 for every cutoff of the wide tiling
 constexpr int kIsMaxSlabs = 160;     // slabs the chunks of one work item cover (<= 128 + 2 TC)
@@ -461,14 +464,11 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
 
 } // namespace
 
-// Worth it when the work items are big: the pipeline's warm-up and tail cost ~10 us per item.  The size of an item in
-// a populated region is the plan's target (seg_target_points: n / (5.4 CUs), at least 2048 points): 7 237 at config C3,
-// 2 048 at C5, where the lock-step kernel stays ahead (0.62 vs 0.69 ms).
 bool interp_stream_pays(const Geom &g, const PlanLayout &L, int64_t n)
 {
     int64_t nsets = g.tiles_per_batch > 0 ? L.ntiles / g.tiles_per_batch : 1;
     if (nsets < 1) nsets = 1;
-    return seg_target_points(n, nsets, device_cu_count()) >= 4000;
+    return stream_items(n, nsets, device_cu_count());
 }
 
 bool interp_stream_supported(const Geom &g)

@@ -23,7 +23,8 @@ int launch_spread_reg(const Geom &g, const PlanLayout &L, const void *plan, cons
 
 // spread_mfma.hip: matrix-core spreading for the wide 3-D tiling (g.wide)
 bool spread_mfma_supported(const Geom &g);
-int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, const float *xs,
+// (xs = coefficients in plan order, planar; with xr != nullptr the kernel fills it from the caller's row-major array)
+int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, const float *xr, float *xs,
                        int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream);
 
 // interp.hip: yr[perm[slot] * Cr + cr] = sum over taps of grid[p, ...]

@@ -81,7 +81,8 @@ struct __align__(16) MfmaLds {
 template <int W, bool OVERFLOW, bool OWNED>
 __global__ void __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *__restrict__ spos,
-                   const float *__restrict__ xs, const int64_t xs_stride, const int Cr,
+                   const int *__restrict__ perm, const float *__restrict__ xr, float *__restrict__ xs,
+                   const int64_t xs_stride, const int Cr,
                    const int plane0, float *__restrict__ grid, const int seg_slabs, const int nsegm,
                    const int *__restrict__ first_end, const int4 *__restrict__ overflow)
 {
@@ -134,7 +135,32 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     const float sc = win_exp_scale(m);
     float norm = win_norm(m);
     norm = norm * norm * norm;
-    const float *const xcol = xs + (int64_t)cr * xs_stride;
+    // coefficients in plan order, one column after the other.  With `perm` the kernel makes that copy itself: the pass
+    // below that finds the item's largest |x| reads the caller's row-major [point][Cr] array through the plan's
+    // permutation and leaves the values in xs (no separate permutation pass over all points: 0.18 ms at C3)
+    float *const xcol = xs + (int64_t)cr * xs_stride;
+    // max |x| over the plan entries [j_begin, j_end), strided over `nthr` threads.  Through the permutation the loads
+    // go out eight at a time: a loop of dependent (index, value) pairs is two HBM latencies per point and thread
+    auto absmax_range = [&](const int j_begin, const int j_end, const int t, const int nthr, float mx) {
+        if (perm) {
+            for (int j0 = j_begin + t; j0 < j_end; j0 += 8 * nthr) {
+                int pj[8];
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) pj[q] = j0 + q * nthr < j_end ? perm[j0 + q * nthr] : -1;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = pj[q] >= 0 ? xr[(int64_t)pj[q] * Cr + cr] : 0.0f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (pj[q] >= 0) xcol[j0 + q * nthr] = v[q];
+                    mx = fmaxf(mx, fabsf(v[q]));
+                }
+            }
+        } else {
+            for (int j = j_begin + t; j < j_end; j += nthr) mx = fmaxf(mx, fabsf(xcol[j]));
+        }
+        return mx;
+    };
     // x is scaled into [-1, 1] by a power of two so that every operand fits f16; undone at the flush.  The scale is
     // this work item's own: the largest |x| among the points of its slab range in its column -- columns, point sets or
     // regions of very different magnitude each keep their full ~22 bits (a single global scale would flush a column
@@ -146,12 +172,10 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
         if (OWNED) {
             for (int k = wave; k < nslab; k += kMfmaThreads / 64) {
                 const int sw = wrap(s_lo + k, g.M);
-                const int p_end = tile_offsets[bin0 + sw + 1];
-                for (int j = tile_offsets[bin0 + sw] + lane; j < p_end; j += 64) mx = fmaxf(mx, fabsf(xcol[j]));
+                mx = absmax_range(tile_offsets[bin0 + sw], tile_offsets[bin0 + sw + 1], lane, 64, mx);
             }
         } else {
-            const int p_end = tile_offsets[bin0 + se];
-            for (int j = tile_offsets[bin0 + sb] + tid; j < p_end; j += kMfmaThreads) mx = fmaxf(mx, fabsf(xcol[j]));
+            mx = absmax_range(tile_offsets[bin0 + sb], tile_offsets[bin0 + se], tid, kMfmaThreads, mx);
         }
         for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
         // non-negative floats order like their bit patterns (inf saturates the scale, which is clamped below)
@@ -280,11 +304,14 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     // atomic traffic of the flushes a load takes longer than one step.  Every request issues exactly four DMA
     // instructions per wave (lanes without a point read a dummy address), so that the consumer can wait with a count.
     int cur = 0;  // slab of this thread's previous K-block (K-blocks only move forward)
-    auto stage_request = [&](const int batch) {
+    // this thread's slot of a batch: plan index of its point (any valid one for a padding slot), whether it has one,
+    // the K-block's slab (unwrapped)
+    auto locate = [&](const int batch, int &idx, int &have, int &slab) {
         const int j = st / kKB, i = st - j * kKB;
         const int q = batch * kNKB + j;
-        const int buf = batch & 1;
-        int have = 0, slab = INT_MAX, idx = 0;
+        have = 0;
+        slab = INT_MAX;
+        idx = 0;
         if (q < total) {
             // sched[lo].x <= q < sched[lo + 1].x; probe four slabs ahead per LDS round trip
             int lo = cur;
@@ -304,12 +331,21 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
             have = idx < L.sched_end[lo];
             if (!have) idx = e0.y;  // any valid point: the value is not used
         }
+    };
+    auto issue_dma = [&](const int batch, const int idx, const int have, const int slab, const float *xsrc) {
+        const int j = st / kKB, i = st - j * kKB;
+        const int buf = batch & 1;
         lds_dma_dword(spos + (int64_t)idx * 3 + 0, &L.raw[buf][0][(wave - kStageWave0) * 64]);
         lds_dma_dword(spos + (int64_t)idx * 3 + 1, &L.raw[buf][1][(wave - kStageWave0) * 64]);
         lds_dma_dword(spos + (int64_t)idx * 3 + 2, &L.raw[buf][2][(wave - kStageWave0) * 64]);
-        lds_dma_dword(xcol + idx, &L.raw[buf][3][(wave - kStageWave0) * 64]);
+        lds_dma_dword(xsrc, &L.raw[buf][3][(wave - kStageWave0) * 64]);
         L.raw_have[buf][st] = have;
         if (i == 0) L.raw_slab[buf][j] = slab;
+    };
+    auto stage_request = [&](const int batch) {
+        int idx, have, slab;
+        locate(batch, idx, have, slab);
+        issue_dma(batch, idx, have, slab, xcol + idx);
     };
     auto stage_convert = [&](MfmaStage &S, const int batch, const bool newest_in_flight) {
         const int buf = batch & 1;
@@ -437,6 +473,18 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                 const f16x8 ah = __builtin_bit_cast(f16x8, uh), al = __builtin_bit_cast(f16x8, ul);
                 // one column tile after the other (their B fragments are not live at the same time: the kernel sits at
                 // the register limit, and a spill here costs more than the interleaving of the two chains gains)
+                if (OWNED && hv == 3) {
+                    // (plans of the owned tiling are not ordered by column group: nearly every K-block touches both
+                    // tiles, and the two independent chains interleave)
+                    const f16x8 b0h = O.bfrag[j][0][0][lane], b0l = O.bfrag[j][0][1][lane];
+                    const f16x8 b1h = O.bfrag[j][1][0][lane], b1l = O.bfrag[j][1][1][lane];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0h, ah, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1h, ah, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0l, ah, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1l, ah, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0h, al, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1h, al, acc1, 0, 0, 0);
+                } else {
                 if (hv & 1) {
                     const f16x8 b0h = O.bfrag[j][0][0][lane], b0l = O.bfrag[j][0][1][lane];
                     if constexpr (OWNED) {
@@ -461,6 +509,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1l, acc1, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1h, acc1, 0, 0, 0);
                     }
+                }
                 }
                 dirty = true;
             }
@@ -507,8 +556,8 @@ bool spread_mfma_supported(const Geom &g) { return g.dim == 3 && g.wide; }
 
 template <int W, bool OWNED>
 static int launch_mfma_t(const Geom &g, const PlanLayout &L, const void *plan, const int *to, const float *spos,
-                         const float *xs, int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes,
-                         float *grid, hipStream_t stream)
+                         const int *perm, const float *xr, float *xs, int64_t n, int64_t Cr, int64_t plane0,
+                         int64_t nplanes, float *grid, hipStream_t stream)
 {
     // Ranges per pencil: about 5-6 workgroups per CU balance the tail of the launch against the 2m+1 halo planes
     // every range flushes on top of its own (measured at C3: 6 ranges 7 % faster than 4, 12 in between).  The count
@@ -530,33 +579,34 @@ static int launch_mfma_t(const Geom &g, const PlanLayout &L, const void *plan, c
     const char *base = (const char *)plan;
     const int *first_end = (const int *)(base + L.off_cursor);
     hipLaunchKernelGGL((spread_mfma_kernel<W, false, OWNED>), blocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to,
-                       spos, xs, L.cap, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, (const int4 *)nullptr);
+                       spos, perm, xr, xs, L.cap, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, (const int4 *)nullptr);
     if (L.two_level) {
         // the pieces the plan cut off dense ranges (none for uniform inputs: the workgroups then leave at once)
         const int4 *overflow = (const int4 *)(base + L.off_tmp);
         const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
         hipLaunchKernelGGL((spread_mfma_kernel<W, true, OWNED>), oblocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g,
-                           to, spos, xs, L.cap, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, overflow);
+                           to, spos, perm, xr, xs, L.cap, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, overflow);
     }
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 template <bool OWNED>
-static int launch_mfma_w(const Geom &g, const PlanLayout &L, const void *plan, const float *xs, int64_t n, int64_t Cr,
-                         int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream)
+static int launch_mfma_w(const Geom &g, const PlanLayout &L, const void *plan, const float *xr, float *xs, int64_t n,
+                         int64_t Cr, int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream)
 {
     const char *base = (const char *)plan;
     const int *to = (const int *)(base + L.off_offsets);
     const float *spos = (const float *)(base + L.off_spos);
+    const int *perm = xr ? (const int *)(base + L.off_perm) : nullptr;
     switch (g.m) {
-    case 1: return launch_mfma_t<4, OWNED>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 2: return launch_mfma_t<6, OWNED>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 3: return launch_mfma_t<8, OWNED>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 4: return launch_mfma_t<10, OWNED>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 5: return launch_mfma_t<12, OWNED>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 6: return launch_mfma_t<14, OWNED>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 7: return launch_mfma_t<16, OWNED>(g, L, plan, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 1: return launch_mfma_t<4, OWNED>(g, L, plan, to, spos, perm, xr, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 2: return launch_mfma_t<6, OWNED>(g, L, plan, to, spos, perm, xr, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 3: return launch_mfma_t<8, OWNED>(g, L, plan, to, spos, perm, xr, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 4: return launch_mfma_t<10, OWNED>(g, L, plan, to, spos, perm, xr, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 5: return launch_mfma_t<12, OWNED>(g, L, plan, to, spos, perm, xr, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 6: return launch_mfma_t<14, OWNED>(g, L, plan, to, spos, perm, xr, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 7: return launch_mfma_t<16, OWNED>(g, L, plan, to, spos, perm, xr, xs, n, Cr, plane0, nplanes, grid, stream);
     }
     set_error("matrix-core spreading supports cutoff 1..7");
     return 1;
@@ -564,7 +614,9 @@ static int launch_mfma_w(const Geom &g, const PlanLayout &L, const void *plan, c
 
 // `n` is the problem's point count (it fixes the work decomposition the plan was built for); the plan may hold more
 // entries than that (owned tiling).  The owned variant writes every cell of the planes: no zero-fill needed.
-int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, const float *xs,
+// xs: the coefficients in plan order, column after column (stride L.cap).  xr == nullptr: the caller has filled it
+// (gather_rows); else the kernel fills it from xr, the row-major [point][Cr] array, through the plan's permutation.
+int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, const float *xr, float *xs,
                        int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream)
 {
     if (nplanes <= 0) return 0;
@@ -572,8 +624,8 @@ int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, con
         if (g.owned) NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(nplanes * g.cells * 4), stream));
         return 0;
     }
-    return g.owned ? launch_mfma_w<true>(g, L, plan, xs, n, Cr, plane0, nplanes, grid, stream)
-                   : launch_mfma_w<false>(g, L, plan, xs, n, Cr, plane0, nplanes, grid, stream);
+    return g.owned ? launch_mfma_w<true>(g, L, plan, xr, xs, n, Cr, plane0, nplanes, grid, stream)
+                   : launch_mfma_w<false>(g, L, plan, xr, xs, n, Cr, plane0, nplanes, grid, stream);
 }
 
 } // namespace nfft
