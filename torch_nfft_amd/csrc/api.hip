@@ -108,6 +108,16 @@ bool column_groups_enabled()
     return on;
 }
 
+int stream_min_item_points()
+{
+    static const int v = [] {
+        const char *env = std::getenv("NFFT_HIP_STREAM_MIN");
+        const int t = env ? std::atoi(env) : 0;
+        return t > 0 ? t : 4000;
+    }();
+    return v;
+}
+
 int owned_override()
 {
     static const int v = [] {

@@ -502,8 +502,10 @@ fwd_axis1_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__rest
 // radix-8 stages then have 64 butterflies, one per lane, and RP rows' worth of loads are in flight.
 constexpr int kWaveCplx = 512;
 constexpr int kRowWaves = 4;       // waves per workgroup
-constexpr int kRowRounds = 1;      // rounds (of RP rows) per wave (round 2, aligned strides: 1 round 0.194 ms at C3 / 12.0 ms at
-                                   // C4-share, 2 rounds 0.212 / 13.7, 4 and 8 worse; 2 or 8 waves per workgroup lose as well)
+constexpr int kR2cRounds = 1;  // the R2C pass reads 2 KB per row: one round in flight is enough (2 rounds 143 us, 1: 140, 3: 146)
+constexpr int kC2rRounds = 2;  // rounds per wave of the C2R pass (all their loads go out first)
+// (rounds processed one after the other, each loading its own rows, lost: 1 round 0.194 ms at C3 / 12.0 ms at C4-share,
+// 2 rounds 0.212 / 13.7, 4 and 8 worse; 2 or 8 waves per workgroup lose as well)
 
 // LDS index swizzle of the per-wave buffer: the butterflies of the later stages touch elements 4, 8 or 32 apart,
 // which without it land in the same banks (up to 16-way conflicts).  Bits 4..2 are XORed with bits 7..5 and bits
@@ -600,24 +602,31 @@ row_r2c_kernel(int KC, int KS, int64_t nrows, const float2 *__restrict__ tw, con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float2 *z = S.z[wave];
     row_tables<LOGL>(S, tw, tid);
-    const int64_t row0 = ((int64_t)blockIdx.x * kRowWaves + wave) * kRowRounds * RP;
-    for (int r = 0; r < kRowRounds; ++r) {
+    const int64_t row0 = ((int64_t)blockIdx.x * kRowWaves + wave) * kR2cRounds * RP;
+    // 16 bytes per lane: the rows arrive in half as many load instructions (C3: 0.198 -> 0.173 ms per pass); the rows
+    // of all rounds of the wave are requested before the first transform
+    float4 v4[kR2cRounds][kWaveCplx / 128];
+#pragma unroll
+    for (int r = 0; r < kR2cRounds; ++r) {
         const int64_t row = row0 + (int64_t)r * RP;
-        if (row >= nrows) break;
-        const int nr = (int)min((int64_t)RP, nrows - row);  // rows of this round (all RP except at the very end)
-        // 16 bytes per lane: the rows arrive in half as many load instructions (C3: 0.198 -> 0.173 ms per pass)
+        const int nr = (int)max((int64_t)0, min((int64_t)RP, nrows - row));
         const float4 *src4 = (const float4 *)(grid + row * M);
-        float4 v4[kWaveCplx / 128];
 #pragma unroll
         for (int q = 0; q < kWaveCplx / 128; ++q) {
             const int n2 = q * 64 + lane;  // pair index: elements 2 n2, 2 n2 + 1
-            v4[q] = 2 * n2 < nr * L ? src4[n2] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v4[r][q] = 2 * n2 < nr * L ? src4[n2] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    }
+#pragma unroll
+    for (int r = 0; r < kR2cRounds; ++r) {
+        const int64_t row = row0 + (int64_t)r * RP;
+        if (row >= nrows) break;
+        const int nr = (int)min((int64_t)RP, nrows - row);  // rows of this round (all RP except at the very end)
 #pragma unroll
         for (int q = 0; q < kWaveCplx / 128; ++q) {
             const int n2 = q * 64 + lane;
-            z[zsw(2 * n2)] = make_float2(v4[q].x, v4[q].y);
-            z[zsw(2 * n2 + 1)] = make_float2(v4[q].z, v4[q].w);
+            z[zsw(2 * n2)] = make_float2(v4[r][q].x, v4[r][q].y);
+            z[zsw(2 * n2 + 1)] = make_float2(v4[r][q].z, v4[r][q].w);
         }
         wave_fft<false, LOGL>(z, S.tw, lane);
         for (int rr = 0; rr < nr; ++rr) {
@@ -646,20 +655,41 @@ row_c2r_kernel(int KC, int KS, int64_t nrows, const float2 *__restrict__ tw, con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float2 *z = S.z[wave];
     row_tables<LOGL>(S, tw, tid);
-    const int64_t row0 = ((int64_t)blockIdx.x * kRowWaves + wave) * kRowRounds * RP;
-    for (int r = 0; r < kRowRounds; ++r) {
+    // The half rows of ALL rounds of the wave are requested before the first transform: a half row is 1 KB, and with
+    // one round in flight per wave the pass was bound by bytes in flight (4.0 TB/s against 5.9 for the R2C pass, which
+    // reads 2 KB per row).  One load per element: beyond the band X is zero, so Z[k] needs X[k] for k < KC and
+    // X[L - k] for L - k < KC, and with KC = L/2 + 1 (the band of an oversampled grid) exactly one of them is kept --
+    // both only at k = L/2, where they are the same element.
+    const int64_t row0 = ((int64_t)blockIdx.x * kRowWaves + wave) * kC2rRounds * RP;
+    constexpr int NIT = kWaveCplx / 64;
+    float2 va[kC2rRounds][NIT];  // (KC == L / 2 + 1 by construction: the launcher passes N / 2 + 1 and L = M / 2 = N)
+#pragma unroll
+    for (int r = 0; r < kC2rRounds; ++r) {
+        const int64_t row = row0 + (int64_t)r * RP;
+        const int nr = (int)max((int64_t)0, min((int64_t)RP, nrows - row));
+        const float2 *src = in + row * KS;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int n = it * 64 + lane;
+            const int rr = n >> LOGL, k = n & (L - 1);
+            const bool live = rr < nr;
+            const int kk = k <= L / 2 ? k : L - k;
+            va[r][it] = live ? src[rr * KS + kk] : make_float2(0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kC2rRounds; ++r) {
         const int64_t row = row0 + (int64_t)r * RP;
         if (row >= nrows) break;
         const int nr = (int)min((int64_t)RP, nrows - row);
-        const float2 *src = in + row * KS;
-#pragma unroll 4
-        for (int n0 = 0; n0 < kWaveCplx; n0 += 64) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
             // Z[k] = (X[k] + conj X[L-k]) + i conj(W_M^k) (X[k] - conj X[L-k]),  X = 0 beyond the band
-            const int n = n0 + lane;
-            const int rr = n >> LOGL, k = n & (L - 1);
-            const bool live = rr < nr;
-            const float2 a = (live && k < KC) ? src[rr * KS + k] : make_float2(0.f, 0.f);
-            float2 b = (live && (L - k) < KC) ? src[rr * KS + L - k] : make_float2(0.f, 0.f);
+            const int n = it * 64 + lane;
+            const int k = n & (L - 1);
+            const float2 v = va[r][it], zero = make_float2(0.f, 0.f);
+            const float2 a = k <= L / 2 ? v : zero;
+            float2 b = k >= L / 2 ? v : zero;
             b.y = -b.y;
             const float2 sum = make_float2(a.x + b.x, a.y + b.y), dif = make_float2(a.x - b.x, a.y - b.y);
             float2 w = S.tw[k];
@@ -871,7 +901,7 @@ template <int LOGL>
 static void launch_rows_t(bool c2r, const Geom &g, int64_t nrows, const float2 *tw, const void *in, void *out,
                           hipStream_t stream)
 {
-    const int64_t per_wg = (int64_t)kRowWaves * kRowRounds * (kWaveCplx >> LOGL);
+    const int64_t per_wg = (int64_t)kRowWaves * (c2r ? kC2rRounds : kR2cRounds) * (kWaveCplx >> LOGL);
     const dim3 blocks((unsigned)((nrows + per_wg - 1) / per_wg));
     if (c2r)
         hipLaunchKernelGGL((row_c2r_kernel<LOGL>), blocks, dim3(kRowWaves * 64), 0, stream, g.N / 2 + 1, compact_stride(g), nrows, tw,
@@ -885,6 +915,7 @@ static int launch_rows(bool c2r, const Geom &g, int64_t nplanes, const float2 *t
                        hipStream_t stream)
 {
     const int64_t nrows = nplanes * g.M * g.M;
+    // (the kept band of a row is N/2 + 1 of its M/2 = N complex points: what the C2R pass's single load per element assumes)
     switch (g.M) {
     case 128: launch_rows_t<6>(c2r, g, nrows, tw, in, out, stream); break;
     case 256: launch_rows_t<7>(c2r, g, nrows, tw, in, out, stream); break;

@@ -289,7 +289,8 @@ inline int seg_base_runs(int64_t n, int64_t nsets, int64_t pencils, int M, int n
 }
 // Work items big enough for the streamed gather (interp_stream.hip: its pipeline costs ~10 us of warm-up and tail per
 // item): 7 237 points per item at config C3, the minimum of 2 048 at C5, where the lock-step kernel stays ahead.
-inline bool stream_items(int64_t n, int64_t nsets, int ncu) { return seg_target_points(n, nsets, ncu) >= 4000; }
+int stream_min_item_points();  // api.hip: 4000, or NFFT_HIP_STREAM_MIN (tuning)
+inline bool stream_items(int64_t n, int64_t nsets, int ncu) { return seg_target_points(n, nsets, ncu) >= stream_min_item_points(); }
 int device_cu_count();  // api.hip: CU count of the current device
 int current_device();
 // "done once per device" flag for per-kernel set-up (hipFuncSetAttribute is per device): a process may drive several

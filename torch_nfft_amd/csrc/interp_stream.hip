@@ -36,10 +36,7 @@ namespace {
 
 constexpr int kIsThreads = 1024;
 constexpr int kIsWaves = kIsThreads / 64;
-#ifndef IS_PRODUCERS
-#define IS_PRODUCERS 4
-#endif
-constexpr int kIsProducers = IS_PRODUCERS;      // measured at C3: 3 producers 1.50 ms, 4: 1.41, 5: 1.50 (each owns 16 / 4 ring slots)
+constexpr int kIsProducers = 4;      // measured at C3: 3 producers 1.50 ms, 4: 1.41, 5: 1.50 (each owns 16 / 4 ring slots)
 constexpr int kIsConsumers = kIsWaves - kIsProducers;
 constexpr int kIsRing = 16;          // resident planes: TC + 2m+1 = 16 for every cutoff of the wide tiling
 constexpr int kIsMaxSlabs = 160;     // slabs the chunks of one work item cover (<= 128 + 2 TC)
@@ -77,9 +74,10 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
                      const int *__restrict__ first_end, const int4 *__restrict__ overflow)
 {
     constexpr int m = W / 2 - 1;
-    constexpr int TC = 17 - W;
+    constexpr int TC = 17 - W;                                   // slabs per chunk
+    constexpr int SPAN = TC + W - 1;                             // planes a chunk's blocks may touch
     constexpr int NKS = NG == 3 ? 2 : 4;  // k-steps of a block
-    static_assert(TC >= 1 && TC + W - 1 == kIsRing, "ring holds exactly one chunk's planes");
+    static_assert(TC >= 1 && SPAN <= kIsRing, "the ring holds a chunk's planes");
     static_assert(128 + 2 * TC <= kIsMaxSlabs, "run tables");
     extern __shared__ __align__(16) unsigned char smem_raw[];
     StreamLds &L = *reinterpret_cast<StreamLds *>(smem_raw);
@@ -113,7 +111,7 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
     }
     // an item owns the chunks whose first slab lies in its range (as in interp_mfma.hip)
     const int k_begin = (sb + TC - 1) / TC;
-    const int k_end = min(g.nta[0], (se + TC - 1) / TC);
+    const int k_end = min((M + TC - 1) / TC, (se + TC - 1) / TC);
     if (k_begin >= k_end) continue;
     const int bin0 = b * g.tiles_per_batch + pencil * g.np0;
     const int s0 = k_begin * TC;                    // first slab of the item's chunks
@@ -171,7 +169,7 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
     if (wave >= kIsConsumers) {
         // ================================ producer: planes z = z_begin + p, + 4, ... ================================
         const int p = wave - kIsConsumers;
-        const int z_begin = k_begin * TC - m, z_end = (k_end - 1) * TC + kIsRing - m;  // planes any chunk of the item needs
+        const int z_begin = k_begin * TC - m, z_end = (k_end - 1) * TC + SPAN - m;  // planes any chunk of the item needs
         // a lane's 4 tasks of a plane: (row, group of 8 columns); 16 consecutive lanes = 16 consecutive rows of one
         // column group -> consecutive 16-byte LDS slots on the way out, half rows of 128 contiguous bytes on the way in
         auto needed = [&](const int z) {
