@@ -692,3 +692,58 @@ def test_forward_many_columns_wave_per_column(tn, monkeypatch, C, complex_out, c
     for c in range(C):
         assert rel_l2(y[:, c], ref[:, c]) < T1W, c
     assert rel_l2(y, ref) < 2e-6
+
+
+@pytest.mark.parametrize("env_extra", [{"NFFT_HIP_STREAM_MIN": "1"}, {"NFFT_HIP_STREAM_MIN": "1", "NFFT_HIP_COLGROUPS": "0"},
+                                       {"NFFT_HIP_XGATHER": "1"}],
+                         ids=["stream+groups", "stream-nogroups", "separate-permutation"])
+def test_streamed_gather_and_column_groups_on_small_problems(env_extra):
+    """The streamed gather and the column-group order of the plan are chosen for big work items only; with
+    NFFT_HIP_STREAM_MIN=1 they run on problems the oracle can check.  Every cutoff of the wide tiling (chunks of 13 ... 1
+    slabs, windows of 4 ... 16 taps), grids whose last pencil is partial, points on pencil and group boundaries, a dense
+    cluster (overflow pieces), empty regions, two point sets: adjoint and forward vs the float64 oracle.  The third case
+    runs the coefficient permutation as a pass of its own (the default does it inside the spreading kernel)."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+import torch_nfft_amd as tn
+from oracle import nfft_ref
+worst = 0.0
+for case, (N, m, n, nsets) in enumerate([(32, 1, 3000, 1), (32, 2, 3000, 1), (64, 3, 5000, 1), (64, 4, 6000, 2), (32, 5, 3000, 1),
+                                         (64, 6, 4000, 1), (32, 7, 2500, 1), (80, 4, 5000, 1)]):
+    rng = np.random.default_rng(100 + case)
+    M = 2 * N
+    pos = (rng.random((n, 3)) - 0.5).astype(np.float32)
+    # a dense cluster, and points exactly on cell / pencil / column-group boundaries of the first pencils
+    pos[:n // 4] = (0.01 * rng.standard_normal((n // 4, 3)) + 0.2).astype(np.float32)
+    W = 2 * m + 2
+    T2 = 65 - W
+    edges = np.array([0, 32 - W, 33 - W, 31, 32, T2 - 1, T2, T2 + 32 - W], dtype=np.float64)
+    k = min(len(edges) * 8, n // 8)
+    pos[n // 4:n // 4 + k, 2] = ((np.resize(edges, k) + rng.integers(0, 2, k) * 0.999) / M - 0.5).astype(np.float32)
+    pos[n // 4:n // 4 + k, 1] = ((rng.integers(0, M, k)) / M - 0.5).astype(np.float32)
+    pos = np.clip(pos, -0.5, np.nextafter(np.float32(0.5), np.float32(0))).astype(np.float32)
+    batch = None
+    bt = None
+    if nsets == 2:
+        batch = (np.arange(n) >= n // 3).astype(np.int64)
+        bt = torch.from_numpy(batch).cuda()
+    x = rng.standard_normal((n, 2)).astype(np.float32)
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(pos).cuda()
+    y = tn.nfft_adjoint(xt, pt, bt, bandwidth=N, cutoff=m)
+    ref = nfft_ref.nfft_adjoint(x, pos, batch, N=N, m=m)
+    e1 = np.linalg.norm(y.cpu().numpy() - ref) / np.linalg.norm(ref)
+    f = tn.nfft_forward(y, pt, bt, cutoff=m)
+    reff = nfft_ref.nfft_forward(y.cpu().numpy(), pos, batch, m=m)
+    e2 = np.linalg.norm(f.cpu().numpy() - reff) / np.linalg.norm(reff)
+    print("CASE", N, m, n, nsets, e1, e2)
+    worst = max(worst, e1, e2)
+print("RESULT", worst)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    assert float(line[1]) < T1W, out.stdout

@@ -107,8 +107,10 @@ __global__ void __launch_bounds__(256) bin_fill_kernel(Geom g, const float *__re
 // first-level bin: (batch, pencil, segment of l1bins plan bins along axis 0)
 __device__ __forceinline__ int pencil_of(const Geom &g, const int cell[3], int64_t b)
 {
-    const int pencil = ((int)b * g.nta[1] + cell[1] / g.Ta[1]) * g.nta[2] + cell[2] / g.Ta[2];
-    return g.l1seg == 1 ? pencil : pencil * g.l1seg + (cell[0] / g.bin0) / g.l1bins;
+    const int pencil = ((int)b * g.nta[1] + div_small(cell[1], g.Ta[1])) * g.nta[2] + div_small(cell[2], g.Ta[2]);
+    if (g.l1seg == 1) return pencil;
+    const int k0 = g.bin0 == 1 ? cell[0] : div_small(cell[0], g.bin0);
+    return pencil * g.l1seg + div_small(k0, g.l1bins);
 }
 
 // first-level bins of a point given by its (up to three) coordinates, internal axis order: one bin, or up to four
@@ -130,7 +132,7 @@ __device__ __forceinline__ int l1_bins_of(const Geom &g, float c0, float c1, flo
     if (g.owned) {
         int pen[4];
         const int k = owned_pencils(g, cell[1], cell[2], pen);
-        const int seg = (cell[0] / g.bin0) / g.l1bins;
+        const int seg = div_small(g.bin0 == 1 ? cell[0] : div_small(cell[0], g.bin0), g.l1bins);
         for (int q = 0; q < k; ++q) bins[q] = ((int)b * g.nta[1] * g.nta[2] + pen[q]) * g.l1seg + seg;
         return k;
     }
@@ -219,7 +221,7 @@ __device__ __forceinline__ int fine_key(const Geom &g, const float4 rec, const i
     int cell[3];
     float fr;
     split_cell(rec.x, g.M, cell[0], fr);
-    int key = cell[0] / g.bin0 - bin_lo;
+    int key = (g.bin0 == 1 ? cell[0] : div_small(cell[0], g.bin0)) - bin_lo;
     if (g.SB > 1) {
         split_cell(rec.y, g.M, cell[1], fr);
         split_cell(rec.z, g.M, cell[2], fr);

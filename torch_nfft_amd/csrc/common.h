@@ -188,11 +188,17 @@ __device__ __forceinline__ void split_cell(float pos, int M, int &cell, float &f
     if (fr < 0.0f) { fr += 1.0f; fl -= 1.0f; }
     if (fr >= 1.0f) { fr -= 1.0f; fl += 1.0f; }
     if (!(fr >= 0.0f && fr < 1.0f)) fr = 0.0f;  // NaN / inf input: keep indices in range
-    // reduce the (possibly huge) integer part before converting
+    // reduce the (possibly huge) integer part before converting: q is in [-1, M] up to the rounding of the quotient
+    // (then one conditional step fixes it); only garbage inputs (|pos| beyond 2^24 cells) take the integer modulo, which
+    // has no hardware instruction (~25 VALU operations that every point of every kernel would pay)
     float q = fl - floorf(fl / Mf) * Mf;
     int c = (int)q;
-    c %= M;
     if (c < 0) c += M;
+    else if (c >= M) c -= M;
+    if ((unsigned)c >= (unsigned)M) {
+        c %= M;
+        if (c < 0) c += M;
+    }
     cell = c;
     frac = fr;
 }
@@ -212,12 +218,20 @@ __device__ __forceinline__ int wrap_near(int v, int M)
     return v;
 }
 
+// a / b for 0 <= a < 2^20, 1 <= b <= 2^10 (cell indices by tile sizes) without the integer division (no hardware
+// instruction: ~30 VALU operations): (a + 0.5) / b lies at least 0.5 / b away from every integer, far more than the
+// rounding of the reciprocal and the product.
+__device__ __forceinline__ int div_small(int a, int b)
+{
+    return (int)(((float)a + 0.5f) * __builtin_amdgcn_rcpf((float)b));
+}
+
 // Plan bin of a point inside its batch: ((j1 * nt2 + j2) * np0 + k0); the bins of one pencil are contiguous.
 __device__ __forceinline__ int tile_of_cells(const Geom &g, const int cell[3])
 {
-    const int k0 = cell[0] / g.bin0;
-    const int j1 = cell[1] / g.Ta[1];
-    const int j2 = cell[2] / g.Ta[2];
+    const int k0 = g.bin0 == 1 ? cell[0] : div_small(cell[0], g.bin0);
+    const int j1 = div_small(cell[1], g.Ta[1]);
+    const int j2 = div_small(cell[2], g.Ta[2]);
     return (j1 * g.nta[2] + j2) * g.np0 + k0;
 }
 
@@ -225,8 +239,8 @@ __device__ __forceinline__ int tile_of_cells(const Geom &g, const int cell[3])
 // Returns their count; pencil index = j1 * nta[2] + j2.
 __device__ __forceinline__ int owned_pencils(const Geom &g, int c1, int c2, int pencil[4])
 {
-    const int a0 = wrap_near(c1 - g.m, g.M) / g.Ta[1], a1 = wrap_near(c1 + g.m + 1, g.M) / g.Ta[1];
-    const int b0 = wrap_near(c2 - g.m, g.M) / g.Ta[2], b1 = wrap_near(c2 + g.m + 1, g.M) / g.Ta[2];
+    const int a0 = div_small(wrap_near(c1 - g.m, g.M), g.Ta[1]), a1 = div_small(wrap_near(c1 + g.m + 1, g.M), g.Ta[1]);
+    const int b0 = div_small(wrap_near(c2 - g.m, g.M), g.Ta[2]), b1 = div_small(wrap_near(c2 + g.m + 1, g.M), g.Ta[2]);
     int k = 0;
     pencil[k++] = a0 * g.nta[2] + b0;
     if (b1 != b0) pencil[k++] = a0 * g.nta[2] + b1;
