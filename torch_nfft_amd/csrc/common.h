@@ -188,10 +188,10 @@ __device__ __forceinline__ void split_cell(float pos, int M, int &cell, float &f
     if (fr < 0.0f) { fr += 1.0f; fl -= 1.0f; }
     if (fr >= 1.0f) { fr -= 1.0f; fl += 1.0f; }
     if (!(fr >= 0.0f && fr < 1.0f)) fr = 0.0f;  // NaN / inf input: keep indices in range
-    // reduce the (possibly huge) integer part before converting: q is in [-1, M] up to the rounding of the quotient
+    // reduce the (possibly huge) integer part before converting: q is in [-M, 2M) whatever the rounding of the quotient
     // (then one conditional step fixes it); only garbage inputs (|pos| beyond 2^24 cells) take the integer modulo, which
     // has no hardware instruction (~25 VALU operations that every point of every kernel would pay)
-    float q = fl - floorf(fl / Mf) * Mf;
+    float q = fl - floorf(fl * __builtin_amdgcn_rcpf(Mf)) * Mf;  // (a quotient off by one is one step off: fixed below)
     int c = (int)q;
     if (c < 0) c += M;
     else if (c >= M) c -= M;

@@ -34,6 +34,8 @@ namespace nfft {
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int kIsThreads = 1024;
 constexpr int kIsWaves = kIsThreads / 64;
 constexpr int kIsProducers = 4;      // measured at C3: 3 producers 1.50 ms, 4: 1.41, 5: 1.50 (each owns 16 / 4 ring slots)
@@ -306,9 +308,10 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
             a0 = a1 = a2 = 0.0f;
             pm = 0;
             if (idx >= 0) {
-                a0 = spos[(int64_t)idx * 3 + 0];
-                a1 = spos[(int64_t)idx * 3 + 1];
-                a2 = spos[(int64_t)idx * 3 + 2];
+                typedef float f32x3 __attribute__((ext_vector_type(3)));
+                f32x3 v;
+                __builtin_memcpy(&v, spos + (int64_t)idx * 3, 12);  // one 12-byte load
+                a0 = v.x; a1 = v.y; a2 = v.z;
                 pm = perm[idx];
             }
         };
@@ -347,12 +350,15 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
             const float dbase2 = valid ? f2 + (float)(m + o2h) : 1.0e4f;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
+                // (packed fp32 math: two values per VALU instruction for the three arithmetic steps)
                 float w[8];
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    const float d = dbase2 - (float)(16 * ks + jj);
-                    const float ev = __builtin_amdgcn_exp2f(fmaf(d * d, sc, 11.0f));  // exp2(sc d^2) * kOpScale
-                    w[jj] = (unsigned)(16 * ks + jj - o2h) < (unsigned)W ? ev : 0.0f;
+                for (int jj = 0; jj < 8; jj += 2) {
+                    const f32x2 d = f32x2{dbase2, dbase2} - f32x2{(float)(16 * ks + jj), (float)(16 * ks + jj + 1)};
+                    const f32x2 arg = __builtin_elementwise_fma(d * d, f32x2{sc, sc}, f32x2{11.0f, 11.0f});
+                    const float e0 = __builtin_amdgcn_exp2f(arg.x), e1 = __builtin_amdgcn_exp2f(arg.y);  // exp2(sc d^2) * kOpScale
+                    w[jj] = (unsigned)(16 * ks + jj - o2h) < (unsigned)W ? e0 : 0.0f;
+                    w[jj + 1] = (unsigned)(16 * ks + jj + 1 - o2h) < (unsigned)W ? e1 : 0.0f;
                 }
                 unsigned h0, h1, h2, h3, p0, p1, p2, p3;
                 split_pair(w[0], w[1], h0, p0);
@@ -362,16 +368,19 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
                 bh[ks] = u32x4{h0, h1, h2, h3};
                 bl[ks] = u32x4{p0, p1, p2, p3};
             }
-            // psi1 of my point on the 16 rows this lane holds of every T_z (MFMA result layout): row = r + 8 q + 4 h
-            float w1[16];
+            // psi1 of my point on the 16 rows this lane holds of every T_z (MFMA result layout): row = r + 8 q + 4 h;
+            // kept as pairs (registers 2 p, 2 p + 1) for the packed FMAs of the reduction
+            f32x2 w1[8];
             const int o1h = c1 - tb1 - 4 * h;
             const float dbase1 = f1 + (float)(m + o1h);
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int rq = (reg & 3) + 8 * (reg >> 2);
-                const float d = dbase1 - (float)rq;
-                const float ev = __builtin_amdgcn_exp2f(sc * d * d);
-                w1[reg] = (unsigned)(rq - o1h) < (unsigned)W ? ev : 0.0f;
+            for (int p = 0; p < 8; ++p) {
+                const int rq0 = ((2 * p) & 3) + 8 * ((2 * p) >> 2), rq1 = rq0 + 1;
+                const f32x2 d = f32x2{dbase1, dbase1} - f32x2{(float)rq0, (float)rq1};
+                const f32x2 arg = d * d * f32x2{sc, sc};
+                const float e0 = __builtin_amdgcn_exp2f(arg.x), e1 = __builtin_amdgcn_exp2f(arg.y);
+                w1[p].x = (unsigned)(rq0 - o1h) < (unsigned)W ? e0 : 0.0f;
+                w1[p].y = (unsigned)(rq1 - o1h) < (unsigned)W ? e1 : 0.0f;
             }
 
             float y = 0.0f;
@@ -434,13 +443,11 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     const float pw_next = plane_weight(nz, pinv_next);
-                    float t0 = 0.0f, t1 = 0.0f;
+                    f32x2 t = {0.0f, 0.0f};
 #pragma unroll
-                    for (int reg = 0; reg < 16; reg += 2) {
-                        t0 = fmaf(w1[reg], acc[reg], t0);
-                        t1 = fmaf(w1[reg + 1], acc[reg + 1], t1);
-                    }
-                    y = fmaf(pw, t0 + t1, y);
+                    for (int p = 0; p < 8; ++p)
+                        t = __builtin_elementwise_fma(w1[p], f32x2{acc[2 * p], acc[2 * p + 1]}, t);  // v_pk_fma_f32
+                    y = fmaf(pw, t.x + t.y, y);
                     pw = pw_next;
                 }
             }
