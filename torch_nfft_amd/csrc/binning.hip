@@ -45,6 +45,10 @@ PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)
     L.off_hist2 = o;   o = align_up(o + (L.two_level ? L.npencils * kSort2Parts * (int64_t)g.l1bins * g.SB * g.CG * 4 : 0), 256);
     L.grouped = L.two_level && g.CG == 3;
     L.off_groups = o;  o = align_up(o + (L.grouped ? L.ntiles * 2 * 4 : 0), 256);
+    // the count passes leave the keys they computed for the scatter passes (two bytes per point / record instead of
+    // two or three more split_cell + tile-index evaluations)
+    L.off_key1 = o;    o = align_up(o + (L.two_level && !g.owned ? n * 2 : 0), 256);
+    L.off_key2 = o;    o = align_up(o + (L.two_level ? L.cap * 2 : 0), 256);
     L.total = o;
     return L;
 }
@@ -163,7 +167,8 @@ constexpr int kSortUnroll = 8;
 
 __global__ void __launch_bounds__(kSortThreads)
 sort1_count_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restrict__ batch, int64_t n, int64_t B,
-                   int npencils, int nblocks, int *__restrict__ hist /* [pencil][block] */)
+                   int npencils, int nblocks, int *__restrict__ hist /* [pencil][block] */,
+                   unsigned short *__restrict__ key1 /* first-level bin of every point (not for the owned tiling) */)
 {
     extern __shared__ int lds_hist[];
     for (int i = threadIdx.x; i < npencils; i += kSortThreads) lds_hist[i] = 0;
@@ -187,6 +192,7 @@ sort1_count_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restr
             int bins[4];
             const int k = l1_bins_of(g, c0[q], c1[q], c2[q], b, bins);
             for (int r = 0; r < k; ++r) atomicAdd(&lds_hist[bins[r]], 1);
+            if (!g.owned) key1[i0 + (int64_t)q * kSortThreads] = (unsigned short)bins[0];
         }
     }
     __syncthreads();
@@ -195,7 +201,8 @@ sort1_count_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restr
 
 __global__ void __launch_bounds__(kSortThreads)
 sort1_scatter_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restrict__ batch, int64_t n, int64_t B,
-                     int npencils, int nblocks, const int *__restrict__ hscan, float4 *__restrict__ tmp)
+                     int npencils, int nblocks, const int *__restrict__ hscan, const unsigned short *__restrict__ key1,
+                     float4 *__restrict__ tmp)
 {
     extern __shared__ int lds_cur[];
     for (int i = threadIdx.x; i < npencils; i += kSortThreads) lds_cur[i] = hscan[(int64_t)i * nblocks + blockIdx.x];
@@ -205,20 +212,27 @@ sort1_scatter_kernel(Geom g, const float *__restrict__ pos, const int64_t *__res
     for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)kSortThreads * kSortUnroll) {
         float c0[kSortUnroll], c1[kSortUnroll], c2[kSortUnroll];
         int64_t bb[kSortUnroll];
+        int kk[kSortUnroll];
 #pragma unroll
         for (int q = 0; q < kSortUnroll; ++q) {
             const int64_t i = i0 + (int64_t)q * kSortThreads;
             const bool live = i < hi;
             load_point(pos, g.dim, i, live, c0[q], c1[q], c2[q]);
-            bb[q] = live && batch ? batch[i] : 0;
+            bb[q] = live && batch && g.owned ? batch[i] : 0;
+            kk[q] = live && !g.owned ? key1[i] : 0;
         }
 #pragma unroll
         for (int q = 0; q < kSortUnroll; ++q) {
             const int64_t i = i0 + (int64_t)q * kSortThreads;
             if (i >= hi) continue;
-            const int64_t b = bb[q] < 0 ? 0 : (bb[q] >= B ? B - 1 : bb[q]);
             int bins[4];
-            const int k = l1_bins_of(g, c0[q], c1[q], c2[q], b, bins);
+            int k = 1;
+            if (!g.owned) {
+                bins[0] = kk[q];  // (left by the count pass)
+            } else {
+                const int64_t b = bb[q] < 0 ? 0 : (bb[q] >= B ? B - 1 : bb[q]);
+                k = l1_bins_of(g, c0[q], c1[q], c2[q], b, bins);
+            }
             for (int r = 0; r < k; ++r) {
                 const int slot = atomicAdd(&lds_cur[bins[r]], 1);
                 tmp[slot] = make_float4(c0[q], c1[q], c2[q], __int_as_float((int)i));
@@ -266,7 +280,7 @@ __device__ __forceinline__ void sort2_range(const int *__restrict__ hscan, int l
 
 __global__ void __launch_bounds__(kSortThreads)
 sort2_count_kernel(Geom g, int nblocks, const int *__restrict__ hscan, const float4 *__restrict__ tmp,
-                   int *__restrict__ hist2 /* [l1][part][key] */)
+                   int *__restrict__ hist2 /* [l1][part][key] */, unsigned short *__restrict__ key2 /* fine key of every record */)
 {
     extern __shared__ int lds2[];
     const int l1 = blockIdx.x, part = blockIdx.y;
@@ -287,7 +301,11 @@ sort2_count_kernel(Geom g, int nblocks, const int *__restrict__ hscan, const flo
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-            if (j0 + q * kSortThreads < r1) atomicAdd(&lds2[fine_key(g, rec[q], bin_lo, col0)], 1);
+            if (j0 + q * kSortThreads < r1) {
+                const int key = fine_key(g, rec[q], bin_lo, col0);
+                atomicAdd(&lds2[key], 1);
+                key2[j0 + q * kSortThreads] = (unsigned short)key;
+            }
     }
     __syncthreads();
     int *out = hist2 + ((int64_t)l1 * kSort2Parts + part) * g.l1bins * g.SB * g.CG;
@@ -296,14 +314,13 @@ sort2_count_kernel(Geom g, int nblocks, const int *__restrict__ hscan, const flo
 
 __global__ void __launch_bounds__(kSortThreads)
 sort2_scatter_kernel(Geom g, int npencils, int nblocks, const int *__restrict__ hscan, const float4 *__restrict__ tmp,
-                     const int *__restrict__ hist2, int *__restrict__ offsets, int *__restrict__ groups,
-                     int *__restrict__ perm, float *__restrict__ spos)
+                     const int *__restrict__ hist2, const unsigned short *__restrict__ key2, int *__restrict__ offsets,
+                     int *__restrict__ groups, int *__restrict__ perm, float *__restrict__ spos)
 {
     extern __shared__ int lds2[];  // [fine keys] this part's cursors, [fine keys] totals over the parts
     const int l1 = blockIdx.x, part = blockIdx.y;
     const int pencil = l1 / g.l1seg, sg = l1 - pencil * g.l1seg;
     const int bin_lo = sg * g.l1bins;
-    const int col0 = (pencil % g.nta[2]) * g.Ta[2];
     const int nt0 = (min(g.np0, bin_lo + g.l1bins) - bin_lo) * g.SB * g.CG;
     const int64_t obase = ((int64_t)pencil * g.np0 + bin_lo) * g.SB;   // first entry of these keys in the offsets table
                                                                         // (one entry per CG ordering keys)
@@ -352,16 +369,18 @@ sort2_scatter_kernel(Geom g, int npencils, int nblocks, const int *__restrict__ 
     __syncthreads();
     for (int j0 = r0 + threadIdx.x; j0 < r1; j0 += kSortThreads * 8) {
         float4 recs[8];
+        int keys[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int j = j0 + q * kSortThreads;
             recs[q] = j < r1 ? tmp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            keys[q] = j < r1 ? key2[j] : 0;  // (left by the count pass)
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             if (j0 + q * kSortThreads >= r1) continue;
             const float4 rec = recs[q];
-            const int slot = atomicAdd(&lds2[fine_key(g, rec, bin_lo, col0)], 1);
+            const int slot = atomicAdd(&lds2[keys[q]], 1);
             perm[slot] = __float_as_int(rec.w);
             if (g.dim == 3) {
                 // one 12-byte store instead of three 4-byte ones (the pass is bound by scattered store requests)
@@ -487,20 +506,21 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
         const int npencils = (int)L.npencils, nblocks = (int)L.nblocks;
         const int64_t items = L.npencils * L.nblocks + 1;
         const size_t lds1 = (size_t)npencils * 4;
+        unsigned short *key1 = (unsigned short *)(base + L.off_key1), *key2 = (unsigned short *)(base + L.off_key2);
         hipLaunchKernelGGL(sort1_count_kernel, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
-                           npencils, nblocks, hist);
+                           npencils, nblocks, hist, key1);
         size_t scan_bytes = 0;
         NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, hist, hscan, (int)items, stream));
         if ((int64_t)scan_bytes > L.scan_bytes) { set_error("scan scratch too small"); return 2; }
         NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(base + L.off_scan, scan_bytes, hist, hscan, (int)items, stream));
         hipLaunchKernelGGL(sort1_scatter_kernel, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
-                           npencils, nblocks, hscan, tmp);
+                           npencils, nblocks, hscan, key1, tmp);
         int *hist2 = (int *)(base + L.off_hist2);
         const size_t lds2 = (size_t)g.l1bins * g.SB * g.CG * 4;
         hipLaunchKernelGGL(sort2_count_kernel, dim3(npencils, kSort2Parts), dim3(kSortThreads), lds2, stream, g, nblocks,
-                           hscan, tmp, hist2);
+                           hscan, tmp, hist2, key2);
         hipLaunchKernelGGL(sort2_scatter_kernel, dim3(npencils, kSort2Parts), dim3(kSortThreads), 2 * lds2, stream, g,
-                           npencils, nblocks, hscan, tmp, hist2, offsets, (int *)(base + L.off_groups), perm, spos);
+                           npencils, nblocks, hscan, tmp, hist2, key2, offsets, (int *)(base + L.off_groups), perm, spos);
         if (g.wide) {
             // the record area is free now: it holds the overflow list of the load-balance split
             NFFT_HIP_CHECK(hipMemsetAsync(tmp, 0, 16, stream));
