@@ -342,8 +342,13 @@ def main():
         W = 2 * m + 2
         mfma = d == 3 and M >= 64 and W <= 16 and os.environ.get("NFFT_HIP_SPREAD", "m")[:1] not in ("l", "r")
         kname = "spread_mfma_kernel<%d, false, false>" % W if mfma else "spread_kernel<%d,%d>" % (d, W)
-        # matrix flops the kernel issues per tap row: 3 MFMA terms x 2 x 32 x 64 x 16 per (plane, 16 points)
-        mfma_flops = n * W * 3 * 2 * 32 * 64 if mfma else 0
+        # matrix flops the kernel issues per tap row: 3 MFMA terms x 2 x 32 x 64 x 16 per (plane, 16 points) -- half of it for
+        # a K-block whose windows lie in one 32-column half of the tile (the plan orders slabs by column group when the
+        # work items are big; K-blocks that straddle a group boundary do both halves, so this is a slight underestimate)
+        T2 = 65 - W
+        grouped = mfma and n / (5.4 * 256) >= 4000 and os.environ.get("NFFT_HIP_COLGROUPS", "1") != "0"
+        half_tiles = (0.5 * (33 - W) + 0.5 * (T2 - 32) + (W - 1)) / T2 if grouped else 1.0
+        mfma_flops = n * W * 3 * 2 * 32 * 64 * half_tiles if mfma else 0
         sp_ms, sp_cnt = stages["spread"]
         sp_avg = sp_ms / max(sp_cnt, 1)
         alg_bytes = n * (4 * d + 4) + (M ** d) * 4  # every point read once, real grid written once
