@@ -8,7 +8,12 @@
 // (T1 + 2m+1 = 32 rows, T2 + 2m+1 = 64 columns).  It runs on v_mfma_f32_32x32x16_f16 with two-way split
 // operands (2^11 x = hi + lo in f16; hi*hi + hi*lo + lo*hi keeps ~22 bits), fp32 accumulators in registers:
 //   * the plan is sorted by single planes ("slabs"); a K-block is 16 points of ONE slab, so the axis-0 weight of
-//     a plane is a wave-uniform row of a small table;
+//     a plane is a wave-uniform row of a small table.  Inside a slab the plan orders the points by the 32-column half of
+//     the tile their window lies in (column groups, common.h): the operand build records which halves a K-block
+//     touches, and the owners skip the 3 MFMAs of an untouched half (a third of all MFMAs at config C3);
+//   * with one or two coefficient columns the kernel permutes `x` itself: the pass that finds the work item's largest
+//     |x| (the f16 operand scale) reads the caller's array through the plan's permutation, eight loads in flight per
+//     thread, and leaves the plan-ordered copy for the staging pipeline;
 //   * one workgroup (16 waves) sweeps a segment of a pencil.  Plane-owner wave w holds the plane z = w (mod NOWN) of
 //     the sliding window in its accumulators: no LDS accumulator, no barrier to accumulate; it flushes its 32 x 64
 //     tile with global atomics (each instruction = two 128-byte row segments) as soon as the sweep has passed it
@@ -26,7 +31,8 @@
 // flush of the padded tiles is what the scatter variant spends its time on (1.3 TB/s chip-wide for float atomics
 // against ~6 TB/s for stores); at the density of config C3 it is not (profiles/r02_flush_variants.txt).
 // Why: ds_add_f32 is unusable on gfx950 and the f64 LDS atomic bounds spread.hip at ~3.7 ms for 1e10 taps
-// (DESIGN.md section 4); here the taps are 1.23 TFLOP of matrix work per launch (0.73 PFLOP/s) and the kernel runs 1.7 ms at C3.
+// (DESIGN.md section 4); here the taps are ~0.7 TFLOP of issued matrix work per launch and the kernel runs 1.75 ms at C3,
+// bound by the sum of its vector and matrix instruction issue (the two do not overlap on a SIMD: scripts/ubench/overlap.hip).
 #include <algorithm>
 #include <climits>
 #include <cstdlib>
