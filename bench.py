@@ -71,12 +71,18 @@ def self_launch(args):
 
 
 def kernel_source_hash():
+    """Hash of the dominant kernel's source files without their // comments and blank lines (an edited comment does not
+    make a measured traffic figure stale, an edited statement does)."""
     h = hashlib.sha1()
     for name in KERNEL_SOURCES:
         path = os.path.join(ROOT, "torch_nfft_amd", "csrc", name)
         if os.path.exists(path):
-            with open(path, "rb") as f:
-                h.update(f.read())
+            with open(path, "r", encoding="utf-8", errors="replace") as f:
+                for line in f:
+                    code = line.split("//", 1)[0].strip()
+                    if code:
+                        h.update(code.encode("utf-8"))
+                        h.update(b"\n")
     return h.hexdigest()[:16]
 
 
