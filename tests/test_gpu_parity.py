@@ -747,3 +747,25 @@ print("RESULT", worst)
     assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
     assert float(line[1]) < T1W, out.stdout
+
+
+@pytest.mark.parametrize("log_n", [17, 18, 20])
+def test_large_1d_grid(tn, log_n):
+    """1-D bandwidths of 2^17 ... 2^20 (the largest the library accepts): cell indices beyond the range in which the
+    point sort derives tile indices from a float reciprocal (common.h div_small), more first-level bins than the
+    two-level sort takes (fallback plan), and frequencies whose square exceeds 2^31 (the roll-off factor once formed
+    k * k in 32-bit integers: every coefficient with |k| >= 46341 was wrong) -- points near both ends of the grid and a
+    cluster, adjoint and forward against the oracle."""
+    rng = np.random.default_rng(2024)
+    n, N, m = 6000, 1 << log_n, 4
+    pos = (rng.random((n, 1)) - 0.5).astype(np.float32)
+    pos[:200, 0] = np.float32(0.5) - rng.random(200).astype(np.float32) * np.float32(1e-4)
+    pos[200:400, 0] = np.float32(-0.5) + rng.random(200).astype(np.float32) * np.float32(1e-4)
+    pos[400:1000, 0] = (0.3 + 1e-3 * rng.standard_normal(600)).astype(np.float32)
+    pos = np.clip(pos, -0.5, np.nextafter(np.float32(0.5), np.float32(0))).astype(np.float32)
+    x = rng.standard_normal(n).astype(np.float32)
+    y = tn.nfft_adjoint(dev(x), dev(pos), None, bandwidth=N, cutoff=m)
+    ref = nfft_ref.nfft_adjoint(x, pos, None, N=N, m=m)
+    assert rel_l2(host(y), ref) < T1
+    f = tn.nfft_forward(y, dev(pos), None, cutoff=m)
+    assert rel_l2(host(f), nfft_ref.nfft_forward(host(y), pos, None, m=m)) < T1

@@ -39,7 +39,7 @@ struct ColGeom {
     float param;        // pi/3 * m / N^2  (phi_hat_inv exponent scale)
 };
 
-__device__ __forceinline__ float phi_hat_inv_f(int k, float param) { return expf((float)(k * k) * param); }
+__device__ __forceinline__ float phi_hat_inv_f(int k, float param) { return expf((float)k * (float)k * param); }
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {

@@ -218,11 +218,12 @@ __device__ __forceinline__ int wrap_near(int v, int M)
     return v;
 }
 
-// a / b for 0 <= a < 2^20, 1 <= b <= 2^10 (cell indices by tile sizes) without the integer division (no hardware
-// instruction: ~30 VALU operations): (a + 0.5) / b lies at least 0.5 / b away from every integer, far more than the
-// rounding of the reciprocal and the product.
+// a / b for cell indices by tile sizes (a >= 0, b >= 1) without the integer division (no hardware instruction: ~30 VALU
+// operations): for a < 2^17, (a + 0.5) / b lies at least 0.5 / b away from every integer and the rounding of the
+// reciprocal and of the product moves it by less than 0.04 / b.  Larger indices (1-D grids beyond 2^16 points) divide.
 __device__ __forceinline__ int div_small(int a, int b)
 {
+    if (a >= (1 << 17)) return a / b;
     return (int)(((float)a + 0.5f) * __builtin_amdgcn_rcpf((float)b));
 }
 

@@ -43,7 +43,8 @@ static SpecGeom make_spec_geom(const Geom &g)
     return s;
 }
 
-__device__ __forceinline__ float phi_hat_inv(int k, float param) { return expf((float)(k * k) * param); }
+// (k * k in float: the integer product overflows from |k| = 46341, i.e. for bandwidths of 2^17 and up)
+__device__ __forceinline__ float phi_hat_inv(int k, float param) { return expf((float)k * (float)k * param); }
 
 // ---------------------------------------------------------------------------------------------
 // adjoint: one thread per (column, band frequency); i2 fastest so that spectrum reads are contiguous.
