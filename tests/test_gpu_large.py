@@ -330,3 +330,23 @@ def test_streamed_interpolation_is_bitwise_reproducible(tn):
     p = pos[idx].cpu().numpy().astype(np.float64)
     exact = (np.exp(-2j * np.pi * (p @ f.T.astype(np.float64))) * vals[None, :].astype(np.complex128)).sum(1)
     assert rel_l2(y0[idx].cpu().numpy(), exact) < T2_M4 + 1e-4  # (the background adds ~1e-8 sqrt(N^3) = 4e-5)
+
+
+def test_grid_2d_16384_squared(tn):
+    """2-D, N = 8192 (oversampled grid of 16384^2 = 2^28 cells, 1 GiB per real plane): the largest 2-D bandwidth whose
+    grid, spectra and rocFFT work area fit comfortably -- index arithmetic beyond 2^27 cells on the narrow tiling.  Adjoint
+    on a frequency subset (with the band's corners) against the exact sums, forward of a sparse spectrum, adjointness."""
+    N, m, n = 8192, 4, 200_000
+    pos, x, y, err = _subset_check_adjoint(tn, 2, N, m, n, 96, seed=611)
+    assert err < T2_M4
+    corners = np.array([[-N // 2, -N // 2], [-N // 2, N // 2 - 1], [N // 2 - 1, -N // 2], [N // 2 - 1, N // 2 - 1], [0, 0]])
+    exact = ndft.ndft_adjoint_subset(x.cpu().numpy()[:, None], pos.cpu().numpy(), corners)[:, 0]
+    got = y[0].cpu().numpy()[tuple((corners + N // 2).T)]
+    assert rel_l2(got, exact) < T2_M4
+    del y
+    xh, yf, errf = _sparse_forward_check(tn, pos, N, m, 6, seed=612)
+    assert errf < T2_M4
+    ya = tn.nfft_adjoint(x, pos, None, bandwidth=N, cutoff=m)
+    lhs = torch.sum(ya * xh.conj())
+    rhs = torch.sum(x.to(torch.complex64) * yf.conj())
+    assert abs(complex(lhs) - complex(rhs)) < 1e-4 * abs(complex(lhs)) + 1e-2
