@@ -401,22 +401,30 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                 O.bfrag[j][1][0][lane] = zero;
                 O.bfrag[j][1][1][lane] = zero;
                 asm volatile("" ::: "memory");  // the 16-bit scatter below must stay behind the zero fill
+                // lane = 4 k + g: point k of the K-block, taps g, g + 4, g + 8 (, g + 12) -- the point's cell and fraction
+                // are read once, the tap loop has a compile-time trip count and no division
                 int touched = 0;
-                for (int e = lane; e < W * kKB; e += 64) {
-                    const int k = e / W, l = e - k * W;
+                {
+                    const int k = lane >> 2, g4 = lane & 3;
                     const int slot = j * kKB + k;
-                    const int col = S.c2[slot] - m + l;
-                    const float d = S.f2[slot] + (float)(m - l);
-                    const float v = __builtin_amdgcn_exp2f(sc * d * d) * kOpScale;
-                    unsigned hi, lo;
-                    split_pair(v, 0.0f, hi, lo);
-                    if ((unsigned)col < 64u) {  // padding slots fail this
-                        const int ln = 32 * (k >> 3) + (col & 31);
-                        _Float16 *ph = (_Float16 *)&O.bfrag[j][col >> 5][0][ln];
-                        _Float16 *pl = (_Float16 *)&O.bfrag[j][col >> 5][1][ln];
-                        ph[k & 7] = __builtin_bit_cast(_Float16, (unsigned short)hi);
-                        pl[k & 7] = __builtin_bit_cast(_Float16, (unsigned short)lo);
-                        touched |= 1 + (col >> 5);
+                    const int c2v = S.c2[slot];
+                    const float f2v = S.f2[slot];
+                    _Float16 *const base_h = (_Float16 *)&O.bfrag[j][0][0][32 * (k >> 3)] + (k & 7);
+#pragma unroll
+                    for (int t = 0; t < (W + 3) / 4; ++t) {
+                        const int l = g4 + 4 * t;
+                        const int col = c2v - m + l;
+                        const float d = f2v + (float)(m - l);
+                        const float v = __builtin_amdgcn_exp2f(sc * d * d) * kOpScale;
+                        unsigned hi, lo;
+                        split_pair(v, 0.0f, hi, lo);
+                        if (l < W && (unsigned)col < 64u) {  // (padding slots fail the second test)
+                            // element [col >> 5][hi/lo][32 (k >> 3) + (col & 31)][k & 7] of bfrag[j]
+                            _Float16 *ph = base_h + (col >> 5) * (2 * 64 * 8) + (col & 31) * 8;
+                            ph[0] = __builtin_bit_cast(_Float16, (unsigned short)hi);
+                            ph[64 * 8] = __builtin_bit_cast(_Float16, (unsigned short)lo);
+                            touched |= 1 + (col >> 5);
+                        }
                     }
                 }
                 // the plan orders a slab's points by column group (common.h): most K-blocks touch one tile only
@@ -429,24 +437,36 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                 const f32x4 zero = 0.0f;
                 for (int e = lane; e < 32 * kPsiStride / 4; e += 64) pz[e] = zero;
                 asm volatile("" ::: "memory");
-                for (int e = lane; e < W * kKB; e += 64) {
-                    const int k = e / W, l = e - k * W;
+                {
+                    const int k = lane >> 2, g4 = lane & 3;  // as above
                     const int slot = j * kKB + k;
-                    const int row = S.c1[slot] - m + l;
-                    const float d = S.f1[slot] + (float)(m - l);
-                    const float v = __builtin_amdgcn_exp2f(sc * d * d);
-                    if ((unsigned)row < 32u) O.psi1[j][row][k] = v;
+                    const int c1v = S.c1[slot];
+                    const float f1v = S.f1[slot];
+#pragma unroll
+                    for (int t = 0; t < (W + 3) / 4; ++t) {
+                        const int l = g4 + 4 * t;
+                        const int row = c1v - m + l;
+                        const float d = f1v + (float)(m - l);
+                        const float v = __builtin_amdgcn_exp2f(sc * d * d);
+                        if (l < W && (unsigned)row < 32u) O.psi1[j][row][k] = v;
+                    }
                 }
             } else {
-                // axis-0 table [tap][point]: x' psi0
-                for (int e = lane; e < W * kKB; e += 64) {
-                    const int l0 = e / kKB, k = e - l0 * kKB;
+                // axis-0 table [tap][point]: x' psi0 (the same lane = 4 k + g mapping)
+                {
+                    const int k = lane >> 2, g4 = lane & 3;
                     const int slot = j * kKB + k;
-                    const float d = S.f0[slot] + (float)(m - l0);
-                    // odd planes accumulate the negated sum (undone at the flush): the sign-independent part of the
-                    // MFMA accumulation's truncation bias then alternates from plane to plane
-                    const float sgn = ((S.slab[j] + l0) & 1) ? -kOpScale : kOpScale;
-                    O.atab[j][l0][k] = S.x[slot] * __builtin_amdgcn_exp2f(sc * d * d) * sgn;
+                    const float f0v = S.f0[slot], xv = S.x[slot];
+                    const int sl = S.slab[j];
+#pragma unroll
+                    for (int t = 0; t < (W + 3) / 4; ++t) {
+                        const int l0 = g4 + 4 * t;
+                        const float d = f0v + (float)(m - l0);
+                        // odd planes accumulate the negated sum (undone at the flush): the sign-independent part of the
+                        // MFMA accumulation's truncation bias then alternates from plane to plane
+                        const float sgn = ((sl + l0) & 1) ? -kOpScale : kOpScale;
+                        if (l0 < W) O.atab[j][l0][k] = xv * __builtin_amdgcn_exp2f(sc * d * d) * sgn;
+                    }
                 }
                 if (lane == 0) O.slab[j] = S.slab[j];
             }
