@@ -352,7 +352,7 @@ def main():
         # a K-block whose windows lie in one 32-column half of the tile (the plan orders slabs by column group when the
         # work items are big; K-blocks that straddle a group boundary do both halves, so this is a slight underestimate)
         T2 = 65 - W
-        grouped = mfma and n / (5.4 * 256) >= 4000 and os.environ.get("NFFT_HIP_COLGROUPS", "1") != "0"
+        grouped = mfma and n / (5.4 * 256) >= 3000 and os.environ.get("NFFT_HIP_COLGROUPS", "1") != "0"
         half_tiles = (0.5 * (33 - W) + 0.5 * (T2 - 32) + (W - 1)) / T2 if grouped else 1.0
         mfma_flops = n * W * 3 * 2 * 32 * 64 * half_tiles if mfma else 0
         sp_ms, sp_cnt = stages["spread"]

@@ -113,7 +113,7 @@ int stream_min_item_points()
     static const int v = [] {
         const char *env = std::getenv("NFFT_HIP_STREAM_MIN");
         const int t = env ? std::atoi(env) : 0;
-        return t > 0 ? t : 4000;
+        return t > 0 ? t : 3000;
     }();
     return v;
 }

@@ -144,7 +144,7 @@ inline Geom make_geom(int dim, int64_t N, int64_t m, bool owned = false)
 
 inline bool owned_supported(int dim, int64_t N, int64_t m) { return make_geom(dim, N, m, true).owned != 0; }
 
-// Sparse inputs take the owner-computes spreading kernel: below ~0.03 points per grid cell the atomic flush of the
+// Sparse inputs take the owner-computes spreading kernel: below ~0.026 points per grid cell the atomic flush of the
 // padded tiles (and the zero-fill in front of it) costs more than spreading 1.46x as many plan entries
 // (measured crossover on MI355X; NFFT_HIP_OWNED=0 / 1 forces the choice).
 int owned_override();  // api.hip: -1 auto, 0 never, 1 whenever supported
@@ -157,7 +157,7 @@ inline bool choose_owned(int dim, int64_t N, int64_t m, int64_t n, int64_t B, do
     const int ov = owned_override();
     if (ov >= 0) return ov != 0;
     const double cells = 8.0 * (double)N * (double)N * (double)N * (double)(B > 0 ? B : 1) * occupied;
-    return n > 0 && (double)n < 0.03 * cells;
+    return n > 0 && (double)n < 0.026 * cells;
 }
 
 // ---- device helpers --------------------------------------------------------
@@ -303,8 +303,9 @@ inline int seg_base_runs(int64_t n, int64_t nsets, int64_t pencils, int M, int n
     return (int)(r > kSegMax ? kSegMax : r);
 }
 // Work items big enough for the streamed gather (interp_stream.hip: its pipeline costs ~10 us of warm-up and tail per
-// item): 7 237 points per item at config C3, the minimum of 2 048 at C5, where the lock-step kernel stays ahead.
-int stream_min_item_points();  // api.hip: 4000, or NFFT_HIP_STREAM_MIN (tuning)
+// item): 7 237 points per item at config C3, the minimum of 2 048 at C5, where the lock-step kernel stays ahead
+// (0.60 vs 0.83 ms); at 5e6 points (3 617 per item) the streamed kernel + column groups win by 0.1 ms per step.
+int stream_min_item_points();  // api.hip: 3000, or NFFT_HIP_STREAM_MIN (tuning)
 inline bool stream_items(int64_t n, int64_t nsets, int ncu) { return seg_target_points(n, nsets, ncu) >= stream_min_item_points(); }
 int device_cu_count();  // api.hip: CU count of the current device
 int current_device();
