@@ -45,7 +45,7 @@ namespace nfft {
 
 namespace {
 
-constexpr int kKB = 16;        // points per K-block (the MFMA K dimension)
+constexpr int kKB = 16;        // points per K-block (the MFMA K dimension; the table builds map lane = 4 * point + tap group: 4 kKB = 64)
 constexpr int kNKB = 8;        // K-blocks per batch
 constexpr int kSlots = kKB * kNKB;
 constexpr int kMfmaThreads = 1024;
