@@ -16,6 +16,7 @@
 // "band+" is k in [-N/2, N/2]: the extra +N/2 row feeds the Hermitian mirror g_hat[-k] = conj(g_hat[k])
 // that reconstructs the k2 < 0 half of the spectrum from the stored k2 >= 0 half.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -270,9 +271,19 @@ __device__ __forceinline__ void stage_twiddles(float2 *ltw, const float2 *__rest
 }
 
 // ---- adjoint, axis 1:  S[plane][u0][u1][Mh] -> T[plane][u0][NB][KC] --------------------------------------
+// LOGM / LOGNC > 0: grid size and tile width known at compile time (the stage sequence, the digit reversal and the
+// twiddle masks fold to constants); 0: run-time values of the geometry
+template <int LOGM, int LOGNC>
 __global__ void __launch_bounds__(kFftThreads)
-adj_axis1_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__restrict__ S, float2 *__restrict__ T)
+adj_axis1_kernel(ColGeom cg_in, const float2 *__restrict__ tw, const float2 *__restrict__ S, float2 *__restrict__ T)
 {
+    ColGeom cg = cg_in;
+    if constexpr (LOGM > 0) {
+        cg.M = 1 << LOGM;
+        cg.logM = LOGM;
+        cg.NC = 1 << LOGNC;
+        cg.logNC = LOGNC;
+    }
     extern __shared__ float2 smem[];
     float2 *ltw = smem;
     float2 *buf = smem + cg.M / 2;
@@ -319,11 +330,18 @@ __device__ __forceinline__ void apply_mult(const void *__restrict__ mult, int ki
 // ---- adjoint, axis 0 + roll-off:  T -> y[b][N][N][N][C] ---------------------------------------------------
 // F = forward DFT of the real plane at (k0, k1, k2 >= 0).  g_hat (e^{+} convention) = conj(F); the k2 < 0 half
 // follows from g_hat[-k] = conj(g_hat[k]) = F[k].
-template <bool XCOMPLEX, bool REAL_OUT>
+template <int LOGM, int LOGNC, bool XCOMPLEX, bool REAL_OUT>
 __global__ void __launch_bounds__(kFftThreads)
-adj_axis0_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__restrict__ T, int64_t C, int64_t col0,
+adj_axis0_kernel(ColGeom cg_in, const float2 *__restrict__ tw, const float2 *__restrict__ T, int64_t C, int64_t col0,
                  void *__restrict__ yv, const void *__restrict__ mult, int mult_kind)
 {
+    ColGeom cg = cg_in;
+    if constexpr (LOGM > 0) {
+        cg.M = 1 << LOGM;
+        cg.logM = LOGM;
+        cg.NC = 1 << LOGNC;
+        cg.logNC = LOGNC;
+    }
     extern __shared__ float2 smem[];
     float2 *ltw = smem;
     float2 *buf = smem + cg.M / 2;
@@ -399,11 +417,18 @@ __device__ __forceinline__ float2 band_value(const void *__restrict__ xhat, int6
     return make_float2(((const float *)xhat)[idx], 0.f);
 }
 
-template <bool XCOMPLEX>
+template <int LOGM, int LOGNC, bool XCOMPLEX>
 __global__ void __launch_bounds__(kFftThreads)
-fwd_axis0_kernel(ColGeom cg, const float2 *__restrict__ tw, const void *__restrict__ xhat, int64_t C, int ppc,
+fwd_axis0_kernel(ColGeom cg_in, const float2 *__restrict__ tw, const void *__restrict__ xhat, int64_t C, int ppc,
                  int64_t plane0, float2 *__restrict__ T)
 {
+    ColGeom cg = cg_in;
+    if constexpr (LOGM > 0) {
+        cg.M = 1 << LOGM;
+        cg.logM = LOGM;
+        cg.NC = 1 << LOGNC;
+        cg.logNC = LOGNC;
+    }
     extern __shared__ float2 smem[];
     float2 *ltw = smem;
     float2 *buf = smem + cg.M / 2;
@@ -447,9 +472,17 @@ fwd_axis0_kernel(ColGeom cg, const float2 *__restrict__ tw, const void *__restri
 }
 
 // ---- forward, axis 1:  T[plane][u0][NB][KC] -> S[plane][u0][u1][Mh]  (columns k2 >= KC are zero) ----------
+template <int LOGM, int LOGNC>
 __global__ void __launch_bounds__(kFftThreads)
-fwd_axis1_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__restrict__ T, float2 *__restrict__ S)
+fwd_axis1_kernel(ColGeom cg_in, const float2 *__restrict__ tw, const float2 *__restrict__ T, float2 *__restrict__ S)
 {
+    ColGeom cg = cg_in;
+    if constexpr (LOGM > 0) {
+        cg.M = 1 << LOGM;
+        cg.logM = LOGM;
+        cg.NC = 1 << LOGNC;
+        cg.logNC = LOGNC;
+    }
     extern __shared__ float2 smem[];
     float2 *ltw = smem;
     float2 *buf = smem + cg.M / 2;
@@ -827,6 +860,24 @@ int64_t colfft_scratch_bytes(const Geom &g, int64_t nplanes)
     return align_up(nplanes * (int64_t)g.M * (g.N + 1) * compact_stride(g) * 8, 256) + align_up((int64_t)g.M * 4, 256);
 }
 
+// Calls f(log2 M, log2 NC) as integral constants for the sizes the column kernels are specialised for -- 512^3 grids
+// with their default tile widths (one and two tile buffers) -- and f(0, 0), the run-time version, otherwise
+// (NFFT_HIP_COL_GENERIC=1: always).  Compile-time sizes take 6-14 % off a pass at M = 512 (C3: 110 / 90 / 110 / 120 ->
+// 103 / 84 / 98 / 103 us); the same specialisation for 256^3 grids measured 6 % SLOWER (C4-share column passes 16.55 ->
+// 17.5 ms) and is not instantiated.
+template <typename F>
+static void col_dispatch(const ColGeom &cg, F &&f)
+{
+    static const bool generic = [] {
+        const char *env = std::getenv("NFFT_HIP_COL_GENERIC");
+        return env && env[0] == '1';
+    }();
+    using std::integral_constant;
+    if (!generic && cg.logM == 9 && cg.logNC == 3) return f(integral_constant<int, 9>{}, integral_constant<int, 3>{});
+    if (!generic && cg.logM == 9 && cg.logNC == 2) return f(integral_constant<int, 9>{}, integral_constant<int, 2>{});
+    return f(integral_constant<int, 0>{}, integral_constant<int, 0>{});
+}
+
 int launch_colfft_adjoint(const Geom &g, const float2 *spec, bool compact, void *scratch, int64_t scratch_planes,
                           int64_t C, int x_is_complex, int real_output, int64_t plane0, int64_t nplanes, void *y,
                           const void *mult, int mult_kind, hipStream_t stream)
@@ -838,8 +889,12 @@ int launch_colfft_adjoint(const Geom &g, const float2 *spec, bool compact, void 
     {
         const ColGeom cg = make_col_geom(g, false, compact);
         const dim3 grid((cg.KC + cg.NC - 1) / cg.NC, g.M, (unsigned)nplanes);
-        allow_lds(adj_axis1_kernel, col_lds_bytes(cg, false));
-        hipLaunchKernelGGL(adj_axis1_kernel, grid, dim3(kFftThreads), col_lds_bytes(cg, false), stream, cg, tw, spec, T);
+        const size_t lds = col_lds_bytes(cg, false);
+        col_dispatch(cg, [&](auto lm, auto ln) {
+            constexpr int LM = decltype(lm)::value, LN = decltype(ln)::value;
+            allow_lds(adj_axis1_kernel<LM, LN>, lds);
+            hipLaunchKernelGGL((adj_axis1_kernel<LM, LN>), grid, dim3(kFftThreads), lds, stream, cg, tw, spec, T);
+        });
     }
     {
         const bool two = x_is_complex != 0;
@@ -848,17 +903,20 @@ int launch_colfft_adjoint(const Geom &g, const float2 *spec, bool compact, void 
         const int64_t col0 = plane0 / ppc, ncols = nplanes / ppc;
         const dim3 grid((cg.KC + cg.NC - 1) / cg.NC, cg.NB, (unsigned)ncols);
         const size_t lds = col_lds_bytes(cg, two);
-        allow_lds(adj_axis0_kernel<true, true>, lds);
-        allow_lds(adj_axis0_kernel<true, false>, lds);
-        allow_lds(adj_axis0_kernel<false, true>, lds);
-        allow_lds(adj_axis0_kernel<false, false>, lds);
-        if (two) {
-            if (real_output) hipLaunchKernelGGL((adj_axis0_kernel<true, true>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, C, col0, y, mult, mult_kind);
-            else hipLaunchKernelGGL((adj_axis0_kernel<true, false>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, C, col0, y, mult, mult_kind);
-        } else {
-            if (real_output) hipLaunchKernelGGL((adj_axis0_kernel<false, true>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, C, col0, y, mult, mult_kind);
-            else hipLaunchKernelGGL((adj_axis0_kernel<false, false>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, C, col0, y, mult, mult_kind);
-        }
+        col_dispatch(cg, [&](auto lm, auto ln) {
+            constexpr int LM = decltype(lm)::value, LN = decltype(ln)::value;
+            auto go = [&](auto kernel) {
+                allow_lds(kernel, lds);
+                hipLaunchKernelGGL(kernel, grid, dim3(kFftThreads), lds, stream, cg, tw, T, C, col0, y, mult, mult_kind);
+            };
+            if (two) {
+                if (real_output) go(adj_axis0_kernel<LM, LN, true, true>);
+                else go(adj_axis0_kernel<LM, LN, true, false>);
+            } else {
+                if (real_output) go(adj_axis0_kernel<LM, LN, false, true>);
+                else go(adj_axis0_kernel<LM, LN, false, false>);
+            }
+        });
     }
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
@@ -875,18 +933,24 @@ int launch_colfft_forward(const Geom &g, const void *xhat, void *scratch, int64_
     const ColGeom cg = make_col_geom(g, false, compact);
     const size_t lds = col_lds_bytes(cg, false);
     const int ppc = real_output ? 1 : 2;
-    allow_lds(fwd_axis0_kernel<true>, lds);
-    allow_lds(fwd_axis0_kernel<false>, lds);
-    allow_lds(fwd_axis1_kernel, lds);
-    {
-        const dim3 grid((cg.KC + cg.NC - 1) / cg.NC, cg.NB, (unsigned)nplanes);
-        if (x_is_complex) hipLaunchKernelGGL((fwd_axis0_kernel<true>), grid, dim3(kFftThreads), lds, stream, cg, tw, xhat, C, ppc, plane0, T);
-        else hipLaunchKernelGGL((fwd_axis0_kernel<false>), grid, dim3(kFftThreads), lds, stream, cg, tw, xhat, C, ppc, plane0, T);
-    }
-    {
-        const dim3 grid(((compact ? cg.KC : cg.Mh) + cg.NC - 1) / cg.NC, g.M, (unsigned)nplanes);
-        hipLaunchKernelGGL(fwd_axis1_kernel, grid, dim3(kFftThreads), lds, stream, cg, tw, T, spec);
-    }
+    col_dispatch(cg, [&](auto lm, auto ln) {
+        constexpr int LM = decltype(lm)::value, LN = decltype(ln)::value;
+        {
+            const dim3 grid((cg.KC + cg.NC - 1) / cg.NC, cg.NB, (unsigned)nplanes);
+            if (x_is_complex) {
+                allow_lds(fwd_axis0_kernel<LM, LN, true>, lds);
+                hipLaunchKernelGGL((fwd_axis0_kernel<LM, LN, true>), grid, dim3(kFftThreads), lds, stream, cg, tw, xhat, C, ppc, plane0, T);
+            } else {
+                allow_lds(fwd_axis0_kernel<LM, LN, false>, lds);
+                hipLaunchKernelGGL((fwd_axis0_kernel<LM, LN, false>), grid, dim3(kFftThreads), lds, stream, cg, tw, xhat, C, ppc, plane0, T);
+            }
+        }
+        {
+            const dim3 grid(((compact ? cg.KC : cg.Mh) + cg.NC - 1) / cg.NC, g.M, (unsigned)nplanes);
+            allow_lds(fwd_axis1_kernel<LM, LN>, lds);
+            hipLaunchKernelGGL((fwd_axis1_kernel<LM, LN>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, spec);
+        }
+    });
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }
