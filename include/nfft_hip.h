@@ -33,11 +33,21 @@ extern "C" {
 #define NFFT_HIP_EWORKSPACE 2 /* workspace missing or too small */
 #define NFFT_HIP_EFFT 3       /* rocFFT plan creation/execution failed (reference: "Failed to create CUFFT plan", core_cuda.cu:255-268) */
 #define NFFT_HIP_EHIP 4       /* HIP runtime error (reference aborts the process, cuda_utils.cu:7-14; we report) */
+#define NFFT_HIP_EKERNEL 5    /* a kernel of an earlier call on this device reported a fault (nfft_hip_check_status) */
 
-#define NFFT_HIP_ABI_VERSION 2
+#define NFFT_HIP_ABI_VERSION 3
 
 int nfft_hip_abi_version(void);
 const char *nfft_hip_last_error(void);
+
+/* Faults that only a running kernel can detect -- a bounded wait inside the streamed interpolation kernel ran out,
+ * a batch index outside [0, batch_size) in the middle of the batch vector -- are raised in a host-mapped status block
+ * of the device and turned into an error by the NEXT entry point called on that device: it returns NFFT_HIP_EKERNEL
+ * (NFFT_HIP_EINVAL for the batch vector) without running, and clears the flag.  nfft_hip_check_status looks at the
+ * block on demand; with synchronize != 0 it first waits for `stream`, so that a fault of the work just enqueued is
+ * seen.  Replaces CHECK_ERRORS of the reference (csrc/cuda/cuda_utils.cu:5-16: cudaDeviceSynchronize, print,
+ * exit()) for the failures a kernel can only report itself. */
+int nfft_hip_check_status(void *stream, int synchronize);
 
 /* Problem description shared by the entry points below.
  * Mirrors the arguments of the reference operators (csrc/core.cpp:43-105):

@@ -57,7 +57,18 @@ def _worker(rank, world, port, sizes, out):
         ys = mod.nfft_adjoint(x, pos, batch, bandwidth=8, cutoff=2, gather=False, local_op=_oracle_adjoint)
         yf = mod.nfft_forward(xh, pos, batch, cutoff=2, local_op=_oracle_forward)
         yfr = mod.nfft_forward(xh, pos, batch, cutoff=2, real_output=True, gather=False, local_op=_oracle_forward)
-        torch.save({"ya": ya, "ys": ys, "yf": yf, "yfr": yfr, "range": mod.batch_range(B, rank, world),
+        # sharded-input forward: the rank's own slab of the spectrum only (what gather=False adjoint returns)
+        b0, b1 = mod.batch_range(B, rank, world)
+        yfl = mod.nfft_forward(xh[b0:b1].clone(), pos, batch, cutoff=2, local_op=_oracle_forward, x_is_local=True)
+        ypipe = mod.nfft_forward(ys, pos, batch, cutoff=2, gather=False, local_op=_oracle_forward, x_is_local=True)
+        try:
+            mod.nfft_forward(xh, pos, batch, cutoff=2, local_op=_oracle_forward, x_is_local=True)
+            wrong_shape_rejected = B == b1 - b0  # (a world whose rank owns everything: the full spectrum IS the slab)
+        except RuntimeError:
+            wrong_shape_rejected = True
+        torch.save({"ya": ya, "ys": ys, "yf": yf, "yfr": yfr, "yfl": yfl, "ypipe": ypipe,
+                    "rejected": wrong_shape_rejected, "layout": mod.shard_layout(batch, world, pos.shape[0]),
+                    "range": mod.batch_range(B, rank, world),
                     "bounds": mod.point_bounds(batch, B, world, pos.shape[0])}, out + ".%d" % rank)
     finally:
         dist.destroy_process_group()
@@ -83,6 +94,11 @@ def test_sharded_matches_unsharded(tmp_path, sizes):
         assert torch.allclose(res[r]["ys"], full_a[b0:b1], atol=1e-5)
         i0, i1 = res[r]["bounds"][r], res[r]["bounds"][r + 1]
         assert torch.allclose(res[r]["yfr"], full_f[i0:i1].real, atol=1e-5)
+        assert torch.allclose(res[r]["yfl"], full_f, atol=1e-5)  # sharded-input forward, rows gathered (ragged shards)
+        pipe = _oracle_forward(full_a, pos, batch, 2, False)     # adjoint slab -> forward without replicating it
+        assert torch.allclose(res[r]["ypipe"], pipe[i0:i1], atol=1e-4)
+        assert res[r]["rejected"]
+        assert res[r]["layout"] == (B, res[r]["bounds"])
     # shards tile the batch exactly
     assert res[0]["range"][0] == 0 and res[world - 1]["range"][1] == B
     assert res[0]["range"][1] == res[1]["range"][0]

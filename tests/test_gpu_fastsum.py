@@ -157,6 +157,12 @@ def test_gaussian_kernel_matrices(tn):
     assert np.abs(host(A2.T @ dev(x)) - (W / deg[None, :]) @ x).max() < 2e-2
     A3 = kern.adjacency_matrix(post[:n], loop_weight=0, shift="signless")
     assert np.abs(host(A3 @ dev(x)) - (deg[:, None] * x + W @ x)).max() < 2e-2
+    # the attribute / method names code written against the reference reads (matrices.py:120-151)
+    assert np.abs(host(A3.degrees) - deg).max() < 2e-2 and A3.d_inv is None and A3.d_inv_sqrt is None
+    assert np.abs(host(A.d_inv_sqrt) - 1 / np.sqrt(deg)).max() < 2e-2 and A.degrees is None
+    assert np.abs(host(A2.d_inv) - 1 / deg).max() < 2e-2 and np.abs(host(A2.T.d_inv) - 1 / deg).max() < 2e-2
+    xt = dev(x)
+    assert torch.equal(A3.apply_shift(xt, xt), A3.degrees[:, None] * xt + xt) and A2.apply_shift(xt, xt) is xt
 
 
 def test_fastsum_operator_and_checks(tn):

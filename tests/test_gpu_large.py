@@ -123,6 +123,35 @@ def test_clustered_points_overflow_launch(tn):
     assert abs(complex(lhs) - complex(rhs)) < 1e-4 * abs(complex(lhs)) + 1e-2
 
 
+def test_config_c3_clustered_10m(tn):
+    """bench.py's `C3-clustered` leg at its full size: 3-D N=256, m=4, 10^7 points in 8 Gaussian clusters (sigma 0.05,
+    SURVEY.md 8(d)'s second distribution) -- dense slab ranges cut into overflow pieces, over-full slabs, the streamed
+    gather on ragged work items.  Adjoint on a frequency subset vs the exact NDFT, forward of a sparse spectrum vs the
+    exact sum, adjointness between the two, and no device fault left behind."""
+    from torch_nfft_amd import ops
+    N, m, n = 256, 4, 10_000_000
+    gen = torch.Generator(device="cuda").manual_seed(777)
+    centres = torch.rand((8, 3), generator=gen, device="cuda") - 0.5
+    which = torch.randint(0, 8, (n,), generator=gen, device="cuda")
+    pos = centres[which] + 0.05 * torch.randn((n, 3), generator=gen, device="cuda")
+    pos = pos - torch.floor(pos + 0.5)
+    del which
+    x = torch.rand((n,), generator=gen, device="cuda")
+    y = tn.nfft_adjoint(x, pos, None, bandwidth=N, cutoff=m)
+    assert y.shape == (1, N, N, N)
+    rng = np.random.default_rng(778)
+    freqs = rng.integers(-N // 2, N // 2, size=(32, 3))
+    exact = ndft.ndft_adjoint_subset(x.cpu().numpy()[:, None], pos.cpu().numpy(), freqs)[:, 0]
+    got = y[0].cpu().numpy()[tuple((freqs + N // 2).T)]
+    assert rel_l2(got, exact) < T2_M4
+    xh, yf, errf = _sparse_forward_check(tn, pos, N, m, 8, 779)
+    assert yf.shape == (n,) and errf < T2_M4
+    ops.check_status()
+    lhs = torch.sum(y * xh.conj())
+    rhs = torch.sum(x.to(torch.complex64) * yf.conj())
+    assert abs(complex(lhs) - complex(rhs)) < 1e-4 * abs(complex(lhs)) + 1e-2
+
+
 @pytest.mark.parametrize("complex_x,real_output,chunk_planes", [(False, True, 5), (True, False, 5), (True, True, 7),
                                                                  (False, False, 3)])
 def test_config_c4_shape_batched_columns_chunked(tn, monkeypatch, complex_x, real_output, chunk_planes):

@@ -18,6 +18,7 @@ from oracle import ndft, nfft_ref
 pytestmark = pytest.mark.gpu
 
 T1 = 2e-5
+T1N = 2e-6  # narrow-tiling kernels on the sweep sizes: they accumulate in 8-byte LDS cells, observed ~1e-7
 T1W = 2e-6  # matrix-core kernels (3-D grids of 64^3 and up, m <= 7): ~22-bit operands, observed 2e-7; a slip in the f16
             # split (dropping a term costs ~5e-4, a mis-rounded hi part ~1e-5) must not pass
 T2 = {1: 2e-1, 2: 2e-2, 3: 3e-3, 4: 5e-4, 5: 1e-4, 6: 5e-5, 7: 3e-5, 8: 2e-5}
@@ -120,7 +121,7 @@ def test_adjoint_and_forward_vs_oracle(tn, d, N, m, complex_x):
     ya = tn.nfft_adjoint(dev(x), dev(pos), dev(batch), bandwidth=N, cutoff=m)
     assert ya.shape == (B,) + (N,) * d + cols and ya.dtype == torch.complex64
     ref = nfft_ref.nfft_adjoint(x, pos, batch, N=N, m=m)
-    assert rel_l2(host(ya), ref) < T1
+    assert rel_l2(host(ya), ref) < T1N
     assert rel_l2(host(ya), ndft.ndft_adjoint(x, pos, batch, N=N)) < T2[m]
     # forward of a random spectrum
     xh = rng.standard_normal((B,) + (N,) * d + cols).astype(np.float32)
@@ -128,7 +129,7 @@ def test_adjoint_and_forward_vs_oracle(tn, d, N, m, complex_x):
         xh = (xh + 1j * rng.standard_normal(xh.shape)).astype(np.complex64)
     yf = tn.nfft_forward(dev(xh), dev(pos), dev(batch), cutoff=m)
     assert yf.shape == (n,) + cols and yf.dtype == torch.complex64
-    assert rel_l2(host(yf), nfft_ref.nfft_forward(xh, pos, batch, m=m)) < T1
+    assert rel_l2(host(yf), nfft_ref.nfft_forward(xh, pos, batch, m=m)) < T1N
     assert rel_l2(host(yf), ndft.ndft_forward(xh, pos, batch)) < T2[m]
 
 
@@ -617,6 +618,53 @@ def test_owned_spreading_stage_tile_borders(tn, m):
     grid2 = torch.full_like(grid, float("nan"))
     _lib.check(lib.nfft_hip_spread(ctypes.byref(prob), p(plan), p(xt), Cr, p(grid2), p(scratch), s))
     assert torch.equal(grid, grid2)
+
+
+@pytest.mark.parametrize("env_extra", [{"NFFT_HIP_OWNED": "0"}, {"NFFT_HIP_OWNED": "0", "NFFT_HIP_STREAM_MIN": "1"}],
+                         ids=["scatter", "scatter+groups"])
+def test_scatter_spreading_stage_dense_128_cubed(env_extra):
+    """The scatter variant of the matrix-core spreading kernel (the C3 kernel) at stage level: nfft_hip_plan_points +
+    nfft_hip_spread on a dense 128^3 problem (120 000 points = 0.057 per cell, two real columns, a cluster, points on
+    the torus boundary), the spread grid against the oracle's gridding at 2e-6 -- an FFT-side error cannot cancel a
+    spreading-side one here.  Second case: the plan ordered by column groups (K-blocks that skip a half tile), as at C3.
+    Semantics: csrc/cuda/spatial_window_operations.cu:103-171."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, numpy as np, torch, sys
+sys.path.insert(0, %r)
+from torch_nfft_amd import _lib
+from oracle import nfft_ref
+lib = _lib.load()
+rng = np.random.default_rng(77)
+d, N, m, n, Cr = 3, 64, 4, 120000, 2
+M = 2 * N
+pos = (rng.random((n, d)) - 0.5).astype(np.float32)
+pos[:20000] = (0.03 * rng.standard_normal((20000, 3)) + 0.1).astype(np.float32)
+pos[20000:20600] = (np.abs(0.004 * rng.standard_normal((600, 3))) - 0.5).astype(np.float32)  # at the periodic corner
+pos = np.clip(pos, -0.5, np.nextafter(np.float32(0.5), np.float32(0))).astype(np.float32)
+x = rng.standard_normal((n, Cr)).astype(np.float32)
+prob = _lib.Problem(d, n, Cr, 1, N, m)
+p = lambda t: ctypes.c_void_p(t.data_ptr())
+s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+post, xt = torch.from_numpy(pos).cuda(), torch.from_numpy(x).cuda()
+plan = torch.empty(lib.nfft_hip_plan_bytes(ctypes.byref(prob)), dtype=torch.uint8, device="cuda")
+_lib.check(lib.nfft_hip_plan_points(ctypes.byref(prob), p(post), None, p(plan), plan.numel(), s))
+scratch = torch.empty(lib.nfft_hip_spread_scratch_bytes(ctypes.byref(prob), Cr) // 4, device="cuda")
+grid = torch.full((Cr, M, M, M), float("nan"), device="cuda")
+_lib.check(lib.nfft_hip_spread(ctypes.byref(prob), p(plan), p(xt), Cr, p(grid), p(scratch), s))
+_lib.check_status()
+ref = nfft_ref.spread(x, pos, None, N, m).real.reshape((Cr, M, M, M))
+got = grid.cpu().numpy()
+print("FINITE", bool(np.isfinite(got).all()))
+print("RESULT", np.linalg.norm((got - ref).ravel()) / np.linalg.norm(ref.ravel()))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
+    assert "FINITE True" in out.stdout, out.stdout
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    assert float(line[1]) < T1W, out.stdout
 
 
 @pytest.mark.parametrize("owned", ["0", "1"])

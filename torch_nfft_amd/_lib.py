@@ -12,13 +12,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NFFT_HIP_LIB") or os.path.join(_HERE, "libnfft_hip.so")
 CORE_PATH = os.path.join(_HERE, "core.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 POINTS_IN_QUARTER_BALL = 1
 
 # every symbol include/nfft_hip.h declares
 SYMBOLS = (
     "nfft_hip_abi_version",
     "nfft_hip_last_error",
+    "nfft_hip_check_status",
     "nfft_hip_adjoint_workspace_bytes",
     "nfft_hip_forward_workspace_bytes",
     "nfft_hip_adjoint",
@@ -44,7 +45,7 @@ SYMBOLS = (
 )
 STAGES = ("plan", "gather", "zero", "spread", "fft", "rolloff", "interp")
 
-OK, EINVAL, EWORKSPACE, EFFT, EHIP = 0, 1, 2, 3, 4
+OK, EINVAL, EWORKSPACE, EFFT, EHIP, EKERNEL = 0, 1, 2, 3, 4, 5
 
 
 class Problem(ctypes.Structure):
@@ -87,6 +88,8 @@ def load():
     vp, i64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
     lib.nfft_hip_abi_version.restype = ci
     lib.nfft_hip_last_error.restype = ctypes.c_char_p
+    lib.nfft_hip_check_status.argtypes = [vp, ci]
+    lib.nfft_hip_check_status.restype = ci
     for f in (lib.nfft_hip_adjoint_workspace_bytes, lib.nfft_hip_forward_workspace_bytes):
         f.argtypes = [P, ci, ci]
         f.restype = i64
@@ -167,6 +170,15 @@ def profile_collect():
     cnt = (ctypes.c_int64 * n)()
     check(load().nfft_hip_profile_collect(ms, cnt, n))
     return {STAGES[i]: (float(ms[i]), int(cnt[i])) for i in range(n)}
+
+
+def check_status(stream=None, synchronize=True):
+    """Raise if a kernel on the current device has reported a fault (``nfft_hip_check_status``); with ``synchronize``
+    the stream (default: torch's current one) is drained first, so that work just enqueued is covered."""
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    check(load().nfft_hip_check_status(ctypes.c_void_p(stream), 1 if synchronize else 0))
 
 
 def last_error():

@@ -57,7 +57,31 @@ def build(force=False, verbose=True):
         if verbose:
             print("built", LIB)
     build_core(force, hdr, verbose)
+    build_variants(objs, force, hdr, verbose)
     return LIB
+
+
+# Variant libraries for tests that must provoke a device-side failure path: the same objects with ONE source
+# recompiled under a test macro.  Same soname as the product library, so a process that loads the variant first
+# (NFFT_HIP_LIB) binds core.so to it.
+VARIANT_DIR = os.path.join(os.path.dirname(HERE), "tests", "variants")
+VARIANTS = {"spin0": ("interp_stream.hip", ["-DNFFT_HIP_SPIN_LIMIT=0"])}
+
+
+def build_variants(objs, force=False, hdr_mtime=0.0, verbose=True):
+    os.makedirs(VARIANT_DIR, exist_ok=True)
+    for name, (src, defs) in VARIANTS.items():
+        lib = os.path.join(VARIANT_DIR, "libnfft_hip_%s.so" % name)
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(OBJ, "%s.%s.o" % (src, name))
+        if not force and os.path.exists(lib) and os.path.getmtime(lib) >= max(os.path.getmtime(LIB), os.path.getmtime(path), hdr_mtime):
+            continue
+        subprocess.check_call([HIPCC] + FLAGS + defs + ["-x", "hip", "-c", path, "-o", obj])
+        others = [o for o in objs if os.path.basename(o) != src + ".o"]
+        subprocess.check_call([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-Wl,-soname,libnfft_hip.so", "-o", lib] +
+                              others + [obj, "-L" + os.path.join(ROCM, "lib"), "-lrocfft", "-Wl,-rpath," + os.path.join(ROCM, "lib")])
+        if verbose:
+            print("built", lib)
 
 
 def build_core(force=False, hdr_mtime=0.0, verbose=True):

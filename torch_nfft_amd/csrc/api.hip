@@ -12,6 +12,7 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -86,6 +87,65 @@ void DeviceOnce::mark()
 {
     const int dev = current_device();
     if (dev < kMaxDevices) done[dev].store(true, std::memory_order_release);
+}
+
+// ---- device-side failure reports (common.h) ---------------------------------------------------------------
+namespace {
+std::mutex g_status_mutex;
+int *g_status_host = nullptr;      // pinned, portable: kMaxDevices blocks of kStatusInts ints
+bool g_status_failed = false;
+int *status_host_blocks()
+{
+    std::lock_guard<std::mutex> lock(g_status_mutex);
+    if (!g_status_host && !g_status_failed) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, sizeof(int) * kStatusInts * kMaxDevices, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess && p) {
+            std::memset(p, 0, sizeof(int) * kStatusInts * kMaxDevices);
+            g_status_host = (int *)p;
+        } else {
+            (void)hipGetLastError();
+            g_status_failed = true;  // no reports on this platform; the kernels get a null pointer
+        }
+    }
+    return g_status_host;
+}
+const char *const kFaultText[kNumFaults] = {
+    "device fault: the streamed interpolation kernel gave up waiting inside a work item (bounded spin ran out); "
+    "the result of that forward transform is invalid",
+    "Input mismatch: batch holds an index outside [0, batch_size) (the batch vector must be sorted with "
+    "batch[-1] + 1 == batch_size)",
+};
+}  // namespace
+
+int *device_status_block()
+{
+    int *host = status_host_blocks();
+    const int dev = current_device();
+    if (!host || dev >= kMaxDevices) return nullptr;
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, host + dev * kStatusInts, 0) != hipSuccess || !d) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return (int *)d;
+}
+
+// Faults the kernels of the current device have reported since the last look: sets the error text, clears the flags and
+// returns NFFT_HIP_EKERNEL (NFFT_HIP_EINVAL for a bad batch vector); 0 when there is none.
+static int take_pending_fault()
+{
+    int *host = status_host_blocks();
+    const int dev = current_device();
+    if (!host || dev >= kMaxDevices) return 0;
+    volatile int *blk = host + dev * kStatusInts;
+    for (int k = 0; k < kNumFaults; ++k) {
+        if (blk[k]) {
+            blk[k] = 0;
+            set_error(kFaultText[k]);
+            return k == kFaultBatchIndex ? NFFT_HIP_EINVAL : NFFT_HIP_EKERNEL;
+        }
+    }
+    return 0;
 }
 
 SpreadMode spread_mode()
@@ -346,6 +406,12 @@ extern "C" {
 int nfft_hip_abi_version(void) { return NFFT_HIP_ABI_VERSION; }
 const char *nfft_hip_last_error(void) { return g_last_error.c_str(); }
 
+int nfft_hip_check_status(void *stream, int synchronize)
+{
+    if (synchronize) NFFT_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return take_pending_fault();
+}
+
 void nfft_hip_profile_enable(int enable)
 {
     g_profile.store(enable != 0);
@@ -394,6 +460,7 @@ int64_t nfft_hip_plan_bytes(const nfft_hip_problem *p)
 int nfft_hip_plan_points(const nfft_hip_problem *p, const float *pos, const int64_t *batch, void *plan,
                          int64_t plan_bytes, void *stream)
 {
+    if (int rc = take_pending_fault()) return rc;  // a kernel of an earlier call gave up: say so
     if (int rc = validate(p)) return rc;
     const PlanSet ps = plan_set(p);
     if (!plan || plan_bytes < ps.total) { set_error("plan buffer too small"); return NFFT_HIP_EWORKSPACE; }
@@ -411,6 +478,7 @@ int64_t nfft_hip_spread_scratch_bytes(const nfft_hip_problem *p, int64_t real_co
 int nfft_hip_spread(const nfft_hip_problem *p, const void *plan, const float *xr, int64_t real_columns, float *grid,
                     float *scratch, void *stream)
 {
+    if (int rc = take_pending_fault()) return rc;  // a kernel of an earlier call gave up: say so
     if (int rc = validate(p)) return rc;
     const PlanSet ps = plan_set(p);
     const Geom &g = ps.spread_geom();
@@ -427,6 +495,7 @@ int nfft_hip_spread(const nfft_hip_problem *p, const void *plan, const float *xr
 int nfft_hip_interpolate(const nfft_hip_problem *p, const void *plan, const float *grid, int64_t real_columns,
                          float *yr, void *stream)
 {
+    if (int rc = take_pending_fault()) return rc;  // a kernel of an earlier call gave up: say so
     if (int rc = validate(p)) return rc;
     const Geom g = problem_geom(p);
     const PlanLayout L = plan_layout(g, p->num_points, p->batch_size);
@@ -439,6 +508,7 @@ static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64
                         const void *x, int x_is_complex, int real_output, void *y, void *workspace,
                         int64_t workspace_bytes, void *stream, const void *mult = nullptr, int mult_kind = 0)
 {
+    if (int rc = take_pending_fault()) return rc;  // a kernel of an earlier call gave up: say so
     if (int rc = validate(p)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int ppc = x_is_complex ? 2 : 1;
@@ -496,6 +566,7 @@ static int forward_impl(const nfft_hip_problem *p, const float *pos, const int64
                         const void *xhat, int x_is_complex, int real_output, void *y, void *workspace,
                         int64_t workspace_bytes, void *stream)
 {
+    if (int rc = take_pending_fault()) return rc;  // a kernel of an earlier call gave up: say so
     if (int rc = validate(p)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int ppc = real_output ? 1 : 2;

@@ -76,9 +76,10 @@ __device__ __forceinline__ int point_tiles(const Geom &g, const float *__restric
 
 __global__ void __launch_bounds__(256) bin_count_kernel(Geom g, const float *__restrict__ pos,
                                                        const int64_t *__restrict__ batch, int64_t n, int64_t B,
-                                                       int *__restrict__ count)
+                                                       int *__restrict__ count, int *__restrict__ status)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (batch && (batch[i] < 0 || batch[i] >= B)) report_fault(status, kFaultBatchIndex);  // (binned clamped; the next call fails)
         int tiles[4];
         const int k = point_tiles(g, pos, batch, i, B, tiles);
         for (int q = 0; q < k; ++q) atomicAdd(&count[tiles[q]], 1);
@@ -168,7 +169,8 @@ constexpr int kSortUnroll = 8;
 __global__ void __launch_bounds__(kSortThreads)
 sort1_count_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restrict__ batch, int64_t n, int64_t B,
                    int npencils, int nblocks, int *__restrict__ hist /* [pencil][block] */,
-                   unsigned short *__restrict__ key1 /* first-level bin of every point (not for the owned tiling) */)
+                   unsigned short *__restrict__ key1 /* first-level bin of every point (not for the owned tiling) */,
+                   int *__restrict__ status)
 {
     extern __shared__ int lds_hist[];
     for (int i = threadIdx.x; i < npencils; i += kSortThreads) lds_hist[i] = 0;
@@ -188,6 +190,9 @@ sort1_count_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restr
 #pragma unroll
         for (int q = 0; q < kSortUnroll; ++q) {
             if (i0 + (int64_t)q * kSortThreads >= hi) continue;
+            // (the host layer reads the first and the last entry only: an index outside [0, B) in between is binned
+            // clamped, keeps every access in range, and is reported -- the next entry point fails with "Input mismatch")
+            if (bb[q] < 0 || bb[q] >= B) report_fault(status, kFaultBatchIndex);
             const int64_t b = bb[q] < 0 ? 0 : (bb[q] >= B ? B - 1 : bb[q]);
             int bins[4];
             const int k = l1_bins_of(g, c0[q], c1[q], c2[q], b, bins);
@@ -508,7 +513,7 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
         const size_t lds1 = (size_t)npencils * 4;
         unsigned short *key1 = (unsigned short *)(base + L.off_key1), *key2 = (unsigned short *)(base + L.off_key2);
         hipLaunchKernelGGL(sort1_count_kernel, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
-                           npencils, nblocks, hist, key1);
+                           npencils, nblocks, hist, key1, device_status_block());
         size_t scan_bytes = 0;
         NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, hist, hscan, (int)items, stream));
         if ((int64_t)scan_bytes > L.scan_bytes) { set_error("scan scratch too small"); return 2; }
@@ -532,7 +537,8 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
     // counts are accumulated in `cursor`, scanned into `offsets`, then `cursor` restarts at zero
     NFFT_HIP_CHECK(hipMemsetAsync(cursor, 0, (L.ntiles + 1) * 4, stream));
     if (n > 0) {
-        hipLaunchKernelGGL(bin_count_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, g, pos, batch, n, B, cursor);
+        hipLaunchKernelGGL(bin_count_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, g, pos, batch, n, B, cursor,
+                           device_status_block());
     }
     size_t scan_bytes = 0;
     NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, cursor, offsets, (int)(L.ntiles + 1), stream));

@@ -19,6 +19,17 @@ void set_error(const std::string &msg);
         }                                                                                         \
     } while (0)
 
+// ---- device-side failure reports ------------------------------------------
+// A kernel that has to give up (a bounded spin loop of the streamed gather ran out, a batch index outside [0, B))
+// cannot return an error code: it raises a flag in a host-mapped status block instead, one block per device, which
+// the entry points of the C ABI look at (nfft_hip_check_status; every compute entry point refuses to run while a
+// fault is pending).  The reference aborts the process on a device error (csrc/cuda/cuda_utils.cu:5-16); here the
+// next call returns NFFT_HIP_EKERNEL.  One int per fault kind: plain system-scope stores, no read-modify-write
+// across the bus.
+enum DeviceFault { kFaultStreamStall = 0, kFaultBatchIndex = 1, kNumFaults = 2 };
+constexpr int kStatusInts = 16;  // ints per device block (a 64-byte line)
+int *device_status_block();      // api.hip: device-visible address of the current device's block (nullptr: none)
+
 // ---- tiling of the oversampled grid --------------------------------------
 // Internally every problem is 3-D with axes (a0, a1, a2); a2 is the fastest
 // (last) axis of the grid.  For dim < 3 the leading axes are degenerate
@@ -162,6 +173,11 @@ inline bool choose_owned(int dim, int64_t N, int64_t m, int64_t n, int64_t B, do
 
 // ---- device helpers --------------------------------------------------------
 #if defined(__HIPCC__)
+
+__device__ __forceinline__ void report_fault(int *status, DeviceFault kind)
+{
+    if (status) __hip_atomic_store(status + (int)kind, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // Window constants of the reference (Gaussian, oversampling 2):
 //   phi(t) = exp(-t^2 * (3 pi / 4) / m) * sqrt(0.75 / m)

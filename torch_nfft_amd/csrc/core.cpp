@@ -144,15 +144,21 @@ PlanCache &g_cache = *new PlanCache;
 at::Tensor get_plan(const Points &p, const nfft_hip_problem &q)
 {
     void *stream = stream_of(p.pos);
+    // Inference tensors carry no version counter (Tensor::_version() throws): such points are planned afresh in
+    // every call and never enter the cache -- an in-place edit could not be told from the cached state.
+    const bool cacheable = !p.pos.is_inference() && !(p.batch.defined() && p.batch.is_inference());
     PlanKey key;
     key.pos_ptr = p.pos.data_ptr();
-    key.pos_version = (int64_t)p.pos._version();
     key.batch_ptr = p.batch.defined() ? p.batch.data_ptr() : nullptr;
-    key.batch_version = p.batch.defined() ? (int64_t)p.batch._version() : -1;
     key.n = p.n; key.B = p.B; key.N = q.N; key.m = q.m; key.dim = p.dim; key.device = p.pos.device().index();
     key.flags = q.flags;
     std::lock_guard<std::mutex> lock(g_cache.mutex);
-    if (g_cache.enabled) {
+    const bool use_cache = g_cache.enabled && cacheable;
+    if (use_cache) {
+        key.pos_version = (int64_t)p.pos._version();
+        key.batch_version = p.batch.defined() ? (int64_t)p.batch._version() : -1;
+    }
+    if (use_cache) {
         for (PlanEntry &e : g_cache.entries) {
             if (e.plan.defined() && e.key == key) {
                 ++g_cache.hits;
@@ -172,7 +178,7 @@ at::Tensor get_plan(const Points &p, const nfft_hip_problem &q)
     at::Tensor plan = byte_buffer(nbytes, p.pos);
     check_rc(nfft_hip_plan_points(&q, p.pos.data_ptr<float>(), p.batch.defined() ? p.batch.data_ptr<int64_t>() : nullptr,
                                   plan.data_ptr(), nbytes, stream));
-    if (g_cache.enabled) {
+    if (use_cache) {
         PlanEntry *slot = &g_cache.entries[0];
         if (g_cache.entries[0].plan.defined() &&
             (!g_cache.entries[1].plan.defined() || g_cache.entries[1].last_use < g_cache.entries[0].last_use))
@@ -206,6 +212,17 @@ int64_t plan_cache_control(int64_t action)
     case 4: return g_cache.misses;
     }
     TORCH_CHECK(false, "unknown plan cache action");
+}
+
+// Faults a kernel reported since the last look (include/nfft_hip.h nfft_hip_check_status): raises, or returns 0.
+// synchronize != 0 drains the current stream of the current device first.
+int64_t check_status(int64_t synchronize)
+{
+    int dev = 0;
+    TORCH_CHECK(hipGetDevice(&dev) == hipSuccess, "hipGetDevice failed");
+    void *stream = (void *)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA((c10::DeviceIndex)dev).stream();
+    check_rc(nfft_hip_check_status(stream, synchronize != 0 ? 1 : 0));
+    return 0;
 }
 
 // ---- operators ----------------------------------------------------------------------------------------------
@@ -410,4 +427,6 @@ TORCH_LIBRARY(torch_nfft, m)
     m.def("interpolated_kernel_coeffs(Tensor grid_values) -> Tensor", &interpolated_kernel_coeffs);
     // not in the reference: control of the point-plan cache (torch_nfft_amd.ops.plan_cache_*)
     m.def("_plan_cache(int action) -> int", &plan_cache_control);
+    // not in the reference: device-side fault reports (torch_nfft_amd.ops.check_status)
+    m.def("_check_status(int synchronize) -> int", &check_status);
 }

@@ -7,13 +7,17 @@
 // Plans are created once per (kind, dim, M, batch, device) and kept in a bounded least-recently-used cache
 // (kMaxPlans entries: workloads whose number of point sets varies from call to call would otherwise grow it
 // without limit); execution is bound to the caller's stream (the reference leaves cuFFT on the default stream
-// and synchronises the device).
+// and synchronises the device).  An evicted plan is not destroyed on the spot: rocfft_plan_destroy frees device
+// buffers (hipFree: a device-wide synchronisation in the middle of the hot path, and the plan's kernels may still be
+// queued); it is parked with the event recorded behind its last execution and destroyed by a later call once that
+// event has completed.
 #include <rocfft/rocfft.h>
 
 #include <map>
 #include <memory>
 #include <mutex>
 #include <tuple>
+#include <vector>
 
 #include "kernels.h"
 
@@ -23,9 +27,11 @@ namespace {
 struct PlanEntry {
     // shared ownership: an entry evicted from the cache stays alive until the call that is executing it returns
     std::shared_ptr<rocfft_plan_t> plan;
+    std::shared_ptr<ihipEvent_t> done;  // recorded behind every execution of the plan (on the executing stream)
     size_t work_bytes = 0;
     uint64_t last_use = 0;
 };
+std::vector<PlanEntry> g_retired;  // evicted plans whose last execution may still be running
 constexpr size_t kMaxPlans = 32;
 std::mutex g_mutex;
 bool g_setup = false;
@@ -60,6 +66,15 @@ int get_plan(FftKind kind, int dim, int M, int64_t nplanes, PlanEntry &out)
         rocfft_setup();
         g_setup = true;
     }
+    // evicted plans whose work has drained can go now (nobody waits for the device here)
+    for (size_t i = 0; i < g_retired.size();) {
+        if (!g_retired[i].done || hipEventQuery(g_retired[i].done.get()) != hipErrorNotReady) {
+            g_retired[i] = g_retired.back();
+            g_retired.pop_back();
+        } else {
+            ++i;
+        }
+    }
     const auto key = std::make_tuple(dev, (int)kind, dim, M, nplanes);
     auto it = g_plans.find(key);
     if (it != g_plans.end()) {
@@ -88,6 +103,9 @@ int get_plan(FftKind kind, int dim, int M, int64_t nplanes, PlanEntry &out)
         return 3;
     }
     e.plan = std::shared_ptr<rocfft_plan_t>(raw, [](rocfft_plan_t *p) { rocfft_plan_destroy(p); });
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && ev)
+        e.done = std::shared_ptr<ihipEvent_t>(ev, [](ihipEvent_t *p) { (void)hipEventDestroy(p); });
     st = rocfft_plan_get_work_buffer_size(raw, &e.work_bytes);
     if (st != rocfft_status_success) {
         set_error(std::string("rocfft_plan_get_work_buffer_size: ") + status_name(st));
@@ -98,6 +116,7 @@ int get_plan(FftKind kind, int dim, int M, int64_t nplanes, PlanEntry &out)
         auto victim = g_plans.begin();
         for (auto jt = g_plans.begin(); jt != g_plans.end(); ++jt)
             if (jt->second.last_use < victim->second.last_use) victim = jt;
+        g_retired.push_back(victim->second);
         g_plans.erase(victim);
     }
     g_plans[key] = e;
@@ -130,6 +149,7 @@ int fft_execute(FftKind kind, int dim, int M, int64_t nplanes, void *in, void *o
     void *ins[1] = {in};
     void *outs[1] = {out};
     if (st == rocfft_status_success) st = rocfft_execute(e.plan.get(), ins, outs, info);
+    if (e.done) (void)hipEventRecord(e.done.get(), stream);
     if (info) rocfft_execution_info_destroy(info);
     if (st != rocfft_status_success) {
         set_error(std::string("Failed to execute rocFFT plan: ") + status_name(st));

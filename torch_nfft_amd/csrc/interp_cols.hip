@@ -123,7 +123,7 @@ interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
             for (int e = 0; e < 8; ++e) {
                 const int k = 16 * (e >> 1) + 4 * (e & 1);
                 const int c = cbase + k;
-                raw[e] = *(const f32x4 *)(prow + (c >= M ? c - M : c));
+                raw[e] = *(const f32x4_dw *)(prow + (c >= M ? c - M : c));
             }
         } else {
 #pragma unroll

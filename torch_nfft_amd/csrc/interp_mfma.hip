@@ -126,7 +126,7 @@ interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
                 const float *const grow = gplane + (gz * M + g1) * M;
                 const int c0 = tb2 - m + 8 * cg;
                 if (live && c0 >= 0 && c0 + 8 <= M) {
-                    const f32x4 a = *(const f32x4 *)(grow + c0), bq = *(const f32x4 *)(grow + c0 + 4);
+                    const f32x4 a = *(const f32x4_dw *)(grow + c0), bq = *(const f32x4_dw *)(grow + c0 + 4);
                     v[r][0] = a.x; v[r][1] = a.y; v[r][2] = a.z; v[r][3] = a.w;
                     v[r][4] = bq.x; v[r][5] = bq.y; v[r][6] = bq.z; v[r][7] = bq.w;
                 } else {

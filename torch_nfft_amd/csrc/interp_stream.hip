@@ -21,7 +21,9 @@
 //   * a wave claims its next block and fetches that block's points while it works on the current one;
 //   * a producer may overwrite slot z & 15 once every consumer's progress is beyond z - 16.  The slowest consumer
 //     needs planes below progress + 16 only, so the producers can always serve it: no cycle of waits.
-// Every spin loop is bounded (kSpinLimit): a logic error ends the kernel with wrong numbers, never a hung GPU.
+// Every spin loop is bounded (kSpinLimit): a logic error never hangs the GPU; the wave that runs out raises the
+// device's fault flag (common.h report_fault), everybody leaves the item, and the next entry point of the C ABI
+// returns NFFT_HIP_EKERNEL instead of handing out the unfinished rows as a result.
 #include <algorithm>
 #include <climits>
 #include <cstdlib>
@@ -43,7 +45,10 @@ constexpr int kIsConsumers = kIsWaves - kIsProducers;
 constexpr int kIsRing = 16;          // resident planes: TC + 2m+1 = 16 for every cutoff of the wide tiling
 constexpr int kIsMaxSlabs = 160;     // slabs the chunks of one work item cover (<= 128 + 2 TC)
 constexpr int kIsMaxRuns = 3 * kIsMaxSlabs;
-constexpr int kSpinLimit = 1 << 22;
+#ifndef NFFT_HIP_SPIN_LIMIT
+#define NFFT_HIP_SPIN_LIMIT (1 << 22)
+#endif
+constexpr int kSpinLimit = NFFT_HIP_SPIN_LIMIT;  // (the fault-report test builds a variant library with a limit of 0)
 
 struct __align__(16) StreamLds {
     f16x8 frag[kIsRing][4][2][64];   // [plane slot][k-step][hi/lo][lane = 32 (column half) + row]   128 KB
@@ -73,7 +78,7 @@ __global__ void __launch_bounds__(kIsThreads) __attribute__((amdgpu_waves_per_eu
 interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__restrict__ group_starts,
                      const int *__restrict__ perm, const float *__restrict__ spos, const float *__restrict__ grid,
                      const int Cr, const int plane0, float *__restrict__ yr, const int seg_slabs, const int nsegm,
-                     const int *__restrict__ first_end, const int4 *__restrict__ overflow)
+                     const int *__restrict__ first_end, const int4 *__restrict__ overflow, int *__restrict__ status)
 {
     constexpr int m = W / 2 - 1;
     constexpr int TC = 17 - W;                                   // slabs per chunk
@@ -194,8 +199,8 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
                 const float *const grow = gplane + (gz * M + g1) * M;
                 const int c0 = tb2 - m + 8 * cg;
                 if (c0 >= 0 && c0 + 8 <= M) {
-                    v[2 * i] = *(const f32x4 *)(grow + c0);
-                    v[2 * i + 1] = *(const f32x4 *)(grow + c0 + 4);
+                    v[2 * i] = *(const f32x4_dw *)(grow + c0);
+                    v[2 * i + 1] = *(const f32x4_dw *)(grow + c0 + 4);
                 } else {
                     f32x4 a, c;
                     a.x = grow[wrap_near(c0 + 0, M)]; a.y = grow[wrap_near(c0 + 1, M)];
@@ -242,7 +247,11 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
                 int lo = lane < kIsConsumers ? lds_load(&L.progress[lane]) : INT_MAX;
                 for (int off = 32; off >= 1; off >>= 1) lo = min(lo, __shfl_xor(lo, off));
                 if (lo > z - kIsRing || lds_load(&L.abort)) break;
-                if (++spins > kSpinLimit) { lds_store(&L.abort, 1); break; }
+                if (++spins > kSpinLimit) {
+                    lds_store(&L.abort, 1);
+                    if (lane == 0) report_fault(status, kFaultStreamStall);
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(4);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -339,7 +348,10 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
             const int nvalid = __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && h == 0));
             const int z_first = __builtin_amdgcn_readlane(c0, 0) - m;
             const int z_last = __builtin_amdgcn_readlane(c0, nvalid - 1) + m + 1;
-            if (lane == 0) lds_store(&L.progress[wave], z_first);  // planes below are no longer mine
+            // planes below z_first are no longer mine: the fragment reads of the previous block must have completed
+            // before a producer sees this and overwrites their slots
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) lds_store(&L.progress[wave], z_first);
             const int ks0 = NG == 3 ? grp : 0;  // first k-step of the block's group
 
             // B fragments: psi2 of my point on the padded columns 16 (ks0 + ks) + 8 h + jj (zero outside the window).
@@ -401,7 +413,12 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
-            if (bail) { lds_store(&L.abort, 1); break; }
+            if (bail) {
+                // the host learns of it (nfft_hip_check_status): the rows this item has not written stay undefined
+                lds_store(&L.abort, 1);
+                if (lane == 0) report_fault(status, kFaultStreamStall);
+                break;
+            }
             {
                 f16x8 A[NKS][2];
                 const float pinv_first = L.pinv[z_first & (kIsRing - 1)];
@@ -501,6 +518,7 @@ static int launch_is_t(const Geom &g, const PlanLayout &L, const void *plan, con
     const int nsegm = seg_base_runs(n, nsets, pencils, g.M, device_cu_count());
     const int seg_slabs = (g.M + nsegm - 1) / nsegm;
     const dim3 blocks((unsigned)(pencils * nsegm), (unsigned)nplanes);
+    int *const status = device_status_block();
     static DeviceOnce attr_done;
     if (attr_done.first_use()) {
         NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)interp_stream_kernel<W, false, NG>,
@@ -510,12 +528,12 @@ static int launch_is_t(const Geom &g, const PlanLayout &L, const void *plan, con
         attr_done.mark();
     }
     hipLaunchKernelGGL((interp_stream_kernel<W, false, NG>), blocks, dim3(kIsThreads), sizeof(StreamLds), stream, g, to, gs,
-                       perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, (const int4 *)nullptr);
+                       perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, (const int4 *)nullptr, status);
     if (L.two_level) {
         const int4 *overflow = (const int4 *)(base + L.off_tmp);
         const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
         hipLaunchKernelGGL((interp_stream_kernel<W, true, NG>), oblocks, dim3(kIsThreads), sizeof(StreamLds), stream, g, to,
-                           gs, perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, overflow);
+                           gs, perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, overflow, status);
     }
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;

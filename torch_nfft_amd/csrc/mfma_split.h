@@ -9,6 +9,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// four floats at an address that is only dword-aligned (grid rows read at a tile offset): the type says so, the
+// instruction stays global_load_dwordx4
+typedef float f32x4_dw __attribute__((ext_vector_type(4), aligned(4)));
 
 // Operands are scaled to at most 2^11 before the split (values <= 2048 fit f16): the lo parts, ~2^-11 of the
 // value, are then normal f16 numbers instead of subnormals; the consumer multiplies by 2^-11 per operand.

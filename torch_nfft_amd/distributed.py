@@ -24,14 +24,33 @@ def batch_range(batch_size, rank, world):
     return (rank * batch_size) // world, ((rank + 1) * batch_size) // world
 
 
+def _layout(batch, world, n, batch_size=None):
+    """``(B, bounds, last_sets)``: see shard_layout; ``last_sets[r]`` = index of the last non-empty point set among
+    rank r's points (what the forward transform of a shard needs to size its slab).  One read-back for everything."""
+    if batch is None:
+        return 1, [0] + [n] * world, [0] * world  # a single point set lives on rank 0
+    bc = batch.contiguous()
+    if batch_size is None:
+        B_t = bc[-1:] + 1
+    else:
+        B_t = torch.tensor([batch_size], dtype=bc.dtype, device=bc.device)
+    firsts = (torch.arange(world + 1, dtype=bc.dtype, device=bc.device) * B_t) // world  # first point set of every rank
+    idx = torch.searchsorted(bc, firsts)
+    lasts = bc[(idx[1:] - 1).clamp(min=0)] if n > 0 else idx[1:]
+    packed = torch.cat([B_t, idx, lasts]).tolist()
+    return int(packed[0]), [int(v) for v in packed[1:world + 2]], [int(v) for v in packed[world + 2:]]
+
+
+def shard_layout(batch, world, n, batch_size=None):
+    """``(B, bounds)``: the number of point sets and the row boundaries of every rank's points (``world + 1`` ints;
+    ``batch`` is sorted).  ONE blocking read-back for both -- ``B = batch[-1] + 1`` is needed to place the boundaries,
+    so it is formed on the device and comes back with them -- and none at all when there is no batch vector."""
+    return _layout(batch, world, n, batch_size)[:2]
+
+
 def point_bounds(batch, batch_size, world, n):
     """Row boundaries of every rank's points: list of world+1 ints (batch is sorted)."""
-    if batch is None:
-        # a single point set lives on rank 0
-        return [0] + [n] * world
-    firsts = torch.tensor([batch_range(batch_size, r, world)[0] for r in range(world)] + [batch_size],
-                          dtype=batch.dtype, device=batch.device)
-    return [int(v) for v in torch.searchsorted(batch.contiguous(), firsts).tolist()]
+    return shard_layout(batch, world, n, batch_size)[1]
 
 
 def _batch_size(batch):
@@ -39,27 +58,37 @@ def _batch_size(batch):
 
 
 def _all_gather_rows(local, sizes, group):
-    """Concatenate per-rank tensors that differ only in dim 0 (sizes known on every rank)."""
+    """Concatenate per-rank tensors that differ only in dim 0 (sizes known on every rank).  The result is allocated
+    once and every rank's rows land in place: equal shards by one ``all_gather_into_tensor``, ragged ones by an
+    ``all_gather`` onto row views of the result (RCCL takes uneven sizes) or, on backends that do not (gloo), by one
+    broadcast per non-empty shard into its view -- no padded staging copy and no ``cat`` (at C4 either would be another
+    34 GB)."""
     world = len(sizes)
     if world == 1:
         return local
-    smax = max(sizes)
-    if smax == 0:
-        return local
     tail = tuple(local.shape[1:])
-    padded = local
-    if local.shape[0] != smax:
-        padded = local.new_zeros((smax,) + tail)
-        padded[:local.shape[0]] = local
-    out = local.new_empty((world * smax,) + tail)
-    # complex tensors travel as (re, im) pairs: RCCL has no complex dtype
-    if local.is_complex():
-        dist.all_gather_into_tensor(torch.view_as_real(out), torch.view_as_real(padded.contiguous()), group=group)
-    else:
-        dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
-    if all(s == smax for s in sizes):
+    out = local.new_empty((sum(sizes),) + tail)
+    if out.shape[0] == 0:
         return out
-    return torch.cat([out[r * smax:r * smax + sizes[r]] for r in range(world)], dim=0)
+    # complex tensors travel as (re, im) pairs: RCCL has no complex dtype
+    wire_out = torch.view_as_real(out) if out.is_complex() else out
+    wire_in = local.contiguous()
+    wire_in = torch.view_as_real(wire_in) if wire_in.is_complex() else wire_in
+    if all(s == sizes[0] for s in sizes):
+        dist.all_gather_into_tensor(wire_out, wire_in, group=group)
+        return out
+    views = list(torch.split(wire_out, sizes, dim=0))  # contiguous row ranges of the result
+    if dist.get_backend(group) == "nccl" and all(s > 0 for s in sizes):
+        dist.all_gather(views, wire_in, group=group)
+        return out
+    me = dist.get_rank(group)
+    for r, view in enumerate(views):
+        if sizes[r] == 0:
+            continue
+        if r == me:
+            view.copy_(wire_in)
+        dist.broadcast(view, src=r if group is None else dist.get_global_rank(group, r), group=group)
+    return out
 
 
 def shard_adjoint(x, pos, batch, batch_size, rank, world, bandwidth=16, cutoff=3, real_output=False, local_op=None,
@@ -85,9 +114,11 @@ def shard_adjoint(x, pos, batch, batch_size, rank, world, bandwidth=16, cutoff=3
                        dtype=torch.float32 if real_output else torch.complex64)
 
 
-def shard_forward(x, pos, batch, batch_size, rank, world, cutoff=3, real_output=False, local_op=None, bounds=None):
-    """The rows ``[n_r, *cols]`` of the forward transform that rank ``rank`` of ``world`` owns (``x`` is the full
-    ``[B, N.., *cols]`` spectrum; only the rank's own slab is read)."""
+def shard_forward(x, pos, batch, batch_size, rank, world, cutoff=3, real_output=False, local_op=None, bounds=None,
+                  x_is_local=False, last_set=None):
+    """The rows ``[n_r, *cols]`` of the forward transform that rank ``rank`` of ``world`` owns.  ``x`` is the full
+    ``[B, N.., *cols]`` spectrum (only the rank's own slab is read) or, with ``x_is_local``, that slab itself
+    ``[B_r, N.., *cols]`` -- what ``shard_adjoint`` / ``nfft_adjoint(gather=False)`` return."""
     op = local_op or _nfft.nfft_forward
     d = pos.shape[1]
     if bounds is None:
@@ -96,8 +127,15 @@ def shard_forward(x, pos, batch, batch_size, rank, world, cutoff=3, real_output=
     i0, i1 = bounds[rank], bounds[rank + 1]
     if i1 > i0:
         lb = None if batch is None else batch[i0:i1] - b0
-        nb = 1 if lb is None else int(lb[-1].item()) + 1  # the shard's last point sets may be empty
-        return op(x[b0:b0 + nb], pos[i0:i1], lb, cutoff=cutoff, real_output=real_output)
+        # the shard's last point sets may be empty: its slab ends with the last one that holds points
+        if lb is None:
+            nb = 1
+        elif last_set is not None:
+            nb = last_set - b0 + 1
+        else:
+            nb = int(lb[-1].item()) + 1
+        slab = x[:nb] if x_is_local else x[b0:b0 + nb]
+        return op(slab, pos[i0:i1], lb, cutoff=cutoff, real_output=real_output)
     return x.new_zeros((0,) + tuple(x.shape[1 + d:]), dtype=torch.float32 if real_output else torch.complex64)
 
 
@@ -113,23 +151,27 @@ def nfft_adjoint(x, pos, batch=None, bandwidth=16, cutoff=3, real_output=False, 
     rank; each rank transforms its own point sets.  Returns the full ``[B, N.., *cols]`` spectrum on every
     rank (``gather=True``, one all-gather along dim 0) or this rank's ``[B_r, N.., *cols]`` slab."""
     rank, world = _world(group)
-    B = _batch_size(batch)
-    y = shard_adjoint(x, pos, batch, B, rank, world, bandwidth, cutoff, real_output, local_op)
+    B, bounds = shard_layout(batch, world, pos.shape[0])
+    y = shard_adjoint(x, pos, batch, B, rank, world, bandwidth, cutoff, real_output, local_op, bounds)
     if not gather or world == 1:
         return y
     sizes = [batch_range(B, r, world)[1] - batch_range(B, r, world)[0] for r in range(world)]
     return _all_gather_rows(y, sizes, group)
 
 
-def nfft_forward(x, pos, batch=None, cutoff=3, real_output=False, group=None, gather=True, local_op=None):
+def nfft_forward(x, pos, batch=None, cutoff=3, real_output=False, group=None, gather=True, local_op=None,
+                 x_is_local=False):
     """Sharded ``nfft_forward``.  ``x`` is the full ``[B, N.., *cols]`` spectrum (each rank only reads its own
-    slab); returns all ``[n, *cols]`` rows on every rank (``gather=True``) or this rank's rows."""
+    slab) or, with ``x_is_local=True``, this rank's slab ``[B_r, N.., *cols]`` -- the output of
+    ``nfft_adjoint(..., gather=False)``, so an adjoint -> (spectral work) -> forward pipeline never replicates the
+    spectra (34.4 GB per rank at C4).  Returns all ``[n, *cols]`` rows on every rank (``gather=True``) or this rank's
+    rows."""
     rank, world = _world(group)
-    B = _batch_size(batch)
-    if x.shape[0] != B:
+    B, bounds, lasts = _layout(batch, world, pos.shape[0])
+    b0, b1 = batch_range(B, rank, world)
+    if x.shape[0] != (b1 - b0 if x_is_local else B):
         raise RuntimeError("Input mismatch")
-    bounds = point_bounds(batch, B, world, pos.shape[0])
-    y = shard_forward(x, pos, batch, B, rank, world, cutoff, real_output, local_op, bounds)
+    y = shard_forward(x, pos, batch, B, rank, world, cutoff, real_output, local_op, bounds, x_is_local, lasts[rank])
     if not gather or world == 1:
         return y
     sizes = [bounds[r + 1] - bounds[r] for r in range(world)]

@@ -7,7 +7,7 @@ import math
 
 from .coeffs import gaussian_analytic_coeffs, gaussian_interpolated_coeffs
 from .matrices import AdjacencyMatrix, GramMatrix
-from .utils import scale_points_by_norm, shift_points_by_center
+from .utils import compute_points_center, compute_points_radius
 
 
 class GaussianKernel:
@@ -35,27 +35,45 @@ class GaussianKernel:
         else:
             self.coeffs = gaussian_interpolated_coeffs(self.factor * sigma, dim, bandwidth, reg_degree, reg_width)
 
-    def gram_matrix(self, sources, targets=None, source_batch=None, target_batch=None, /, batch=None):
-        if batch is not None:
-            source_batch = batch
-            target_batch = batch
-        same = targets is None
+    def _into_torus(self, sets):
+        """The affine map p -> s_b (p - c_b) that takes the point sets of a problem into the ball the kernel coefficients
+        were computed for.  ``sets`` = [(points, batch), ...] (sources, and targets when they are separate); centre c_b and
+        scale s_b are those of point set b over ALL its points, sources and targets alike (kernel.py:99-117)."""
+        points = [p for p, _ in sets]
+        batches = [b for _, b in sets]
+        tgt, tgt_b = (points[1], batches[1]) if len(sets) == 2 else (None, None)
+
+        def per_set(value, b):  # a per-set quantity [B, ...] or a scalar, laid out along the points of batch vector b
+            return value if b is None else value[b]
+
         if self.shift_by_center:
-            sources, targets = shift_points_by_center(sources, targets, source_batch, target_batch)
-        if self.scale_by_norm is not None:
-            sources, targets = scale_points_by_norm(sources, targets, source_batch, target_batch,
-                                                    factor=self.factor, norm=self.scale_by_norm)
-        else:
-            sources = self.factor * sources
-            if targets is not None:
-                targets = self.factor * targets
-        if same:
-            targets = None
-        return GramMatrix(self.coeffs, sources, targets, source_batch, target_batch, cutoff=self.cutoff)
+            c = compute_points_center(points[0], tgt, batches[0], tgt_b)
+            points = [p - per_set(c, b) for p, b in zip(points, batches)]
+        if self.scale_by_norm is None:
+            return [self.factor * p for p in points]
+        r = compute_points_radius(points[0], points[1] if tgt is not None else None, batches[0], tgt_b,
+                                  norm=self.scale_by_norm)
+        s = self.factor / r
+        return [p * (s if b is None else s[b].unsqueeze(-1)) for p, b in zip(points, batches)]
+
+    def gram_matrix(self, sources, targets=None, source_batch=None, target_batch=None, /, batch=None):
+        """K[i, j] = kernel(source_j - target_i) as a matrix-free operator; ``targets=None``: the symmetric matrix of
+        one point set (the GramMatrix then shares one point plan between its two halves)."""
+        if batch is not None:
+            source_batch = target_batch = batch
+        sets = [(sources, source_batch)]
+        if targets is not None:
+            sets.append((targets, target_batch))
+        mapped = self._into_torus(sets)
+        return GramMatrix(self.coeffs, mapped[0], mapped[1] if targets is not None else None, source_batch,
+                          target_batch, cutoff=self.cutoff)
 
     def __call__(self, *args, **kwargs):
         return self.gram_matrix(*args, **kwargs)
 
     def adjacency_matrix(self, sources, batch=None, loop_weight=1, normalization=None, shift=None, degree_threshold=0):
-        return AdjacencyMatrix(self.gram_matrix(sources, batch=batch), diagonal_offset=loop_weight - 1,
-                               normalization=normalization, shift=shift, degree_threshold=degree_threshold)
+        """Adjacency / Laplacian operator of the kernel graph on one point set; self-loops weigh ``loop_weight``
+        (the kernel's own diagonal is 1, so the Gram diagonal is offset by ``loop_weight - 1``)."""
+        gram = self.gram_matrix(sources, None, batch, batch)
+        return AdjacencyMatrix(gram, diagonal_offset=loop_weight - 1, normalization=normalization, shift=shift,
+                               degree_threshold=degree_threshold)

@@ -135,7 +135,30 @@ class AdjacencyMatrix(AbstractMatrix):
         else:
             self._right = degrees.reciprocal()
 
-    # names the reference exposes for the two scaling steps
+    # names the reference exposes (matrices.py:120-128, 130-151): the degree vector and its inverse powers, the two
+    # scaling steps and the shift step.  (normalization "rw" is stored as "left", the same operator D^-1 W.)
+    @property
+    def degrees(self):
+        return self._shift_diag
+
+    @property
+    def d_inv(self):
+        if self.normalization == "left":
+            return self._left
+        return self._right if self.normalization == "right" else None
+
+    @property
+    def d_inv_sqrt(self):
+        return self._left if self.normalization == "sym" else None
+
+    def apply_shift(self, x, y):
+        """y = A x -> x-dependent shift: D x -+ y (unnormalised) or x -+ y (normalised); ``shift`` "none": y."""
+        sign = _SHIFT_SIGN[self.shift]
+        if sign == 0:
+            return y
+        base = _scale_rows(self._shift_diag, x)
+        return base + y if sign > 0 else base - y
+
     def apply_left_normalization(self, x):
         return _scale_rows(self._left, x)
 
@@ -147,12 +170,7 @@ class AdjacencyMatrix(AbstractMatrix):
         y = self.gram_matrix.apply(z)
         if self.diagonal_offset != 0:
             y = y + self.diagonal_offset * z
-        y = _scale_rows(self._left, y)
-        sign = _SHIFT_SIGN[self.shift]
-        if sign == 0:
-            return y
-        base = _scale_rows(self._shift_diag, x)
-        return base + y if sign > 0 else base - y
+        return self.apply_shift(x, _scale_rows(self._left, y))
 
     def is_symmetric(self):
         return self._left is self._right  # both None, or the same D^-1/2

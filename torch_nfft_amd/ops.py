@@ -32,6 +32,15 @@ def plan_cache_stats():
     return {"hits": int(_ops._plan_cache(3)), "misses": int(_ops._plan_cache(4))}
 
 
+def check_status(synchronize=True):
+    """Raises ``RuntimeError`` if a kernel on the current device has reported a fault since the last look (a bounded
+    wait of the streamed interpolation kernel ran out; a batch index outside ``[0, B)``).  The operators are
+    asynchronous, so such a fault otherwise surfaces in the NEXT operator call on the device; with ``synchronize``
+    (default) the current stream is drained first and the work enqueued so far is covered.  The reference aborts the
+    process on a device error (``csrc/cuda/cuda_utils.cu:5-16``)."""
+    _ops._check_status(1 if synchronize else 0)
+
+
 def nfft_adjoint(pos, x, batch, N, m, real_output):
     """torch_nfft::nfft_adjoint(Tensor pos, Tensor x, Tensor? batch, int N, int m, int real_output) -> Tensor
     (csrc/core.cpp:43-55; driver core_cuda.cu:144-336)."""
