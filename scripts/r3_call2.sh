@@ -1,0 +1,6 @@
+#!/bin/bash
+set -e
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out
+timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $O/r3_t2.log 2>&1
+timeout -k 10 600 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --legs c3clustered,c5 > $O/r3_bench1.json 2> $O/r3_bench1.err

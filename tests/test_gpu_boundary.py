@@ -346,19 +346,21 @@ def test_batch_index_out_of_range_in_the_middle_is_reported(tn):
         pos = dev((rng.random((n, d)) - 0.5).astype(np.float32))
         batch = np.sort(rng.integers(0, 3, n)).astype(np.int64)
         batch[0], batch[-1] = 0, 2
-        bad = batch.copy()
-        bad[n // 2] = 7
-        ops.plan_cache_clear()
-        ops.check_status()
-        tn.nfft_adjoint(dev(rng.standard_normal(n).astype(np.float32)), pos, dev(bad), bandwidth=N, cutoff=3)
-        with pytest.raises(RuntimeError, match="Input mismatch"):
+        for wrong in (7, -1):
+            bad = batch.copy()
+            bad[n // 2] = wrong
+            ops.plan_cache_clear()
             ops.check_status()
-        ops.plan_cache_clear()
-        bad[n // 2] = -1
-        tn.nfft_adjoint(dev(rng.standard_normal(n).astype(np.float32)), pos, dev(bad), bandwidth=N, cutoff=3)
-        torch.cuda.synchronize()
-        with pytest.raises(RuntimeError, match="Input mismatch"):   # without an explicit check: the next call says so
-            tn.nfft_adjoint(dev(rng.standard_normal(n).astype(np.float32)), pos, dev(batch), bandwidth=N, cutoff=3)
+            # the sort kernel raises the flag; whichever entry point looks first reports it -- a later stage of this very
+            # call if the kernel has finished by then, else the explicit check (which drains the stream first)
+            with pytest.raises(RuntimeError, match="Input mismatch: batch holds an index outside"):
+                tn.nfft_adjoint(dev(rng.standard_normal(n).astype(np.float32)), pos, dev(bad), bandwidth=N, cutoff=3)
+                ops.check_status()
+            try:
+                ops.check_status()  # (a later sort pass of the same call -- the owned plan -- may have raised it again)
+            except RuntimeError:
+                pass
+            ops.check_status()  # clear now
         ops.plan_cache_clear()
         y = tn.nfft_adjoint(dev(np.ones(n, dtype=np.float32)), pos, dev(batch), bandwidth=N, cutoff=3)
         ops.check_status()
@@ -392,3 +394,75 @@ def test_operators_under_inference_mode(tn):
     assert rel_l2(host(ys_i), host(ys)) < 1e-6 and rel_l2(host(yb_i), host(ya)) < 1e-6
     after = ops.plan_cache_stats()
     assert after["hits"] == before["hits"]  # inference points never hit (or enter) the cache
+
+
+# ----------------------------------------------------------------------------- adjoint that builds its plan
+
+def test_adjoint_build_plan_carries_coefficients_through_the_sort(tn):
+    """nfft_hip_adjoint_build_plan (what the operator layer calls on a plan-cache miss): the single real coefficient
+    column rides through the plan's sort into the fourth float of the 16-byte plan records and the spreading kernel
+    runs without its permutation pass.  Checked against the oracle, against the two-call route (plan_points +
+    adjoint_planned, which gathers x through the permutation), and the plan it leaves behind is then used with OTHER
+    coefficients (the stored ones must be ignored) and by the forward transform.  Dense problem (scatter kernel) and
+    sparse one (owner-computes kernel: one record per touched tile), two point sets."""
+    from torch_nfft_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(91)
+    for N, n in ((64, 140000), (64, 9000)):
+        m, B = 4, 2
+        pos = (rng.random((n, 3)) - 0.5).astype(np.float32)
+        batch = np.sort(rng.integers(0, B, n)).astype(np.int64)
+        batch[0], batch[-1] = 0, B - 1
+        x = rng.standard_normal(n).astype(np.float32)
+        x2 = rng.standard_normal(n).astype(np.float32)
+        post, bt, xt, x2t = dev(pos), dev(batch), dev(x), dev(x2)
+        prob = _lib.Problem(3, n, 1, B, N, m)
+        nb = lib.nfft_hip_adjoint_workspace_bytes(ctypes.byref(prob), 0, 0)
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        pb = lib.nfft_hip_plan_bytes(ctypes.byref(prob))
+        plan_a = torch.empty(pb, dtype=torch.uint8, device="cuda")
+        plan_b = torch.empty(pb, dtype=torch.uint8, device="cuda")
+        y_fused = torch.empty((B, N, N, N), dtype=torch.complex64, device="cuda")
+        y_two = torch.empty_like(y_fused)
+        y_other = torch.empty_like(y_fused)
+        _lib.check(lib.nfft_hip_adjoint_build_plan(ctypes.byref(prob), _p(post), _p(bt), _p(plan_a), pb, _p(xt), 0, 0,
+                                                   _p(y_fused), _p(ws), nb, _stream()))
+        _lib.check(lib.nfft_hip_plan_points(ctypes.byref(prob), _p(post), _p(bt), _p(plan_b), pb, _stream()))
+        _lib.check(lib.nfft_hip_adjoint_planned(ctypes.byref(prob), _p(plan_b), _p(xt), 0, 0, _p(y_two), _p(ws), nb, _stream()))
+        ref = nfft_ref.nfft_adjoint(x, pos, batch, N=N, m=m)
+        assert rel_l2(host(y_fused), ref) < 2e-6 and rel_l2(host(y_two), ref) < 2e-6
+        # the plan left behind, with other coefficients: what it stores for x must not leak into the result
+        _lib.check(lib.nfft_hip_adjoint_planned(ctypes.byref(prob), _p(plan_a), _p(x2t), 0, 0, _p(y_other), _p(ws), nb, _stream()))
+        assert rel_l2(host(y_other), nfft_ref.nfft_adjoint(x2, pos, batch, N=N, m=m)) < 2e-6
+        # ... and by the forward transform
+        nbf = lib.nfft_hip_forward_workspace_bytes(ctypes.byref(prob), 1, 1)
+        wsf = torch.empty(nbf, dtype=torch.uint8, device="cuda")
+        f_a = torch.empty(n, device="cuda")
+        f_b = torch.empty(n, device="cuda")
+        _lib.check(lib.nfft_hip_forward_planned(ctypes.byref(prob), _p(plan_a), _p(y_two), 1, 1, _p(f_a), _p(wsf), nbf, _stream()))
+        _lib.check(lib.nfft_hip_forward_planned(ctypes.byref(prob), _p(plan_b), _p(y_two), 1, 1, _p(f_b), _p(wsf), nbf, _stream()))
+        assert torch.equal(f_a, f_b)
+        _lib.check_status()
+
+
+def test_operator_cache_miss_and_hit_routes_agree(tn):
+    """torch.ops.torch_nfft.nfft_adjoint on a plan-cache miss builds the plan inside the adjoint call (coefficients carried
+    by the sort); on a hit it takes the planned entry point (coefficients gathered through the permutation).  Same
+    numbers either way, for real (carried) and complex (never carried) coefficients."""
+    from torch_nfft_amd import ops
+    rng = np.random.default_rng(92)
+    n, N, m = 200000, 64, 4
+    pos = dev((rng.random((n, 3)) - 0.5).astype(np.float32))
+    for cplx in (False, True):
+        x = rng.standard_normal(n).astype(np.float32)
+        if cplx:
+            x = (x + 1j * rng.standard_normal(n)).astype(np.complex64)
+        xt = dev(x)
+        ops.plan_cache_clear()
+        s0 = ops.plan_cache_stats()
+        y_miss = tn.nfft_adjoint(xt, pos, None, bandwidth=N, cutoff=m)
+        y_hit = tn.nfft_adjoint(xt, pos, None, bandwidth=N, cutoff=m)
+        s1 = ops.plan_cache_stats()
+        assert s1["misses"] == s0["misses"] + 1 and s1["hits"] == s0["hits"] + 1
+        assert rel_l2(host(y_hit), host(y_miss)) < 1e-6
+        assert rel_l2(host(y_miss), nfft_ref.nfft_adjoint(x, host(pos), None, N=N, m=m)) < 2e-6

@@ -232,12 +232,17 @@ PlanSet plan_set(const nfft_hip_problem *p)
     }
     return ps;
 }
-int build_plans(const PlanSet &ps, const float *pos, const int64_t *batch, int64_t n, int64_t B, void *plan, hipStream_t s)
+// x (optional): the single real coefficient column of the adjoint call the plan is built in; it rides through the sort
+// into the records of the plan the spreading kernel walks (carries_x), which then needs no permutation pass
+int build_plans(const PlanSet &ps, const float *pos, const int64_t *batch, int64_t n, int64_t B, void *plan, hipStream_t s,
+                const float *x = nullptr)
 {
-    if (int rc = launch_plan_points(ps.g, ps.L, pos, batch, n, B, plan, s)) return rc;
-    if (ps.owned) return launch_plan_points(ps.go, ps.Lo, pos, batch, n, B, (char *)plan + ps.off_own, s);
+    if (int rc = launch_plan_points(ps.g, ps.L, pos, batch, n, B, plan, s, ps.owned ? nullptr : x)) return rc;
+    if (ps.owned) return launch_plan_points(ps.go, ps.Lo, pos, batch, n, B, (char *)plan + ps.off_own, s, x);
     return 0;
 }
+// the plan records have room for a coefficient (3-D) and the sort can carry it (two-level path)
+bool carries_x(const PlanSet &ps) { return ps.spread_geom().dim == 3 && ps.spread_layout().two_level; }
 
 // interpolation: matrix-core kernels for the wide 3-D tiling (the wave-per-column one from 4 real columns up) unless
 // NFFT_HIP_GATHER=lds (lane-per-point kernel) or =mfma (always the plane-ring kernel)
@@ -317,13 +322,13 @@ bool spread_permutes(const Geom &g, int64_t Cr)
 
 // xs: the planar copy in plan order; xr: nullptr when the caller has filled xs, else what spread_permutes() reads
 int spread_any(const Geom &g, const PlanLayout &L, const void *plan, const float *xr, float *xs, int64_t n, int64_t Cr,
-               int64_t p0, int64_t np, float *grid, hipStream_t s)
+               int64_t p0, int64_t np, float *grid, hipStream_t s, bool x_in_plan = false)
 {
     if (spread_mfma_supported(g)) {
         // (the owner-computes variant writes every cell itself)
         if (!g.owned) { StageTimer t(kStageZero, s); NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(np * g.cells * 4), s)); }
         StageTimer t(kStageSpread, s);
-        return launch_spread_mfma(g, L, plan, xr, xs, n, Cr, p0, np, grid, s);
+        return launch_spread_mfma(g, L, plan, xr, xs, n, Cr, p0, np, grid, s, x_in_plan);
     }
     if (spread_reg_supported(g) && spread_reg_enabled()) {
         StageTimer t(kStageSpread, s);
@@ -504,9 +509,12 @@ int nfft_hip_interpolate(const nfft_hip_problem *p, const void *plan, const floa
     return gather_any(g, L, plan, grid, p->num_points, real_columns, 0, planes, yr, (hipStream_t)stream);
 }
 
+// ext_plan: an existing plan (pos / batch unused), or nullptr: the plan is built here -- into plan_out if the caller
+// wants to keep it (nfft_hip_adjoint_build_plan), else into the workspace
 static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64_t *batch, const void *ext_plan,
                         const void *x, int x_is_complex, int real_output, void *y, void *workspace,
-                        int64_t workspace_bytes, void *stream, const void *mult = nullptr, int mult_kind = 0)
+                        int64_t workspace_bytes, void *stream, const void *mult = nullptr, int mult_kind = 0,
+                        void *plan_out = nullptr)
 {
     if (int rc = take_pending_fault()) return rc;  // a kernel of an earlier call gave up: say so
     if (int rc = validate(p)) return rc;
@@ -525,19 +533,23 @@ static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64
     float2 *spec = (float2 *)(ws + c.off_spec);
     void *work = ws + c.off_work;
 
-    if (!ext_plan) {
-        StageTimer t(kStagePlan, s);
-        if (int rc = build_plans(c.ps, pos, batch, c.n, c.B, ws + c.off_plan, s)) return rc;
-        plan = ws + c.off_plan;
-    }
     const Geom &gs = c.ps.spread_geom();
     const PlanLayout &Ls = c.ps.spread_layout();
-    const void *plan_s = c.ps.spread_plan(plan);
     const bool fused = spread_permutes(gs, c.Cr);
+    // a plan built in this call takes the (single, real) coefficient column along through its sort: no permutation
+    // pass anywhere (the spreading kernel's own one costs it ~7 % at config C3: a latency-bound prologue per work item)
+    const bool x_in_plan = !ext_plan && fused && c.Cr == 1 && carries_x(c.ps);
+    if (!ext_plan) {
+        StageTimer t(kStagePlan, s);
+        void *dst = plan_out ? plan_out : (void *)(ws + c.off_plan);
+        if (int rc = build_plans(c.ps, pos, batch, c.n, c.B, dst, s, x_in_plan ? (const float *)x : nullptr)) return rc;
+        plan = dst;
+    }
+    const void *plan_s = c.ps.spread_plan(plan);
     if (!fused) { StageTimer t(kStageGather, s); if (int rc = launch_gather_rows(gs, Ls, plan_s, c.n, (const float *)x, c.Cr, xs, s)) return rc; }
     for (int64_t p0 = 0; p0 < c.total_planes; p0 += c.chunk_planes) {
         const int64_t np = std::min(c.chunk_planes, c.total_planes - p0);
-        if (int rc = spread_any(gs, Ls, plan_s, fused ? (const float *)x : nullptr, xs, c.n, c.Cr, p0, np, grid, s)) return rc;
+        if (int rc = spread_any(gs, Ls, plan_s, fused ? (const float *)x : nullptr, xs, c.n, c.Cr, p0, np, grid, s, x_in_plan)) return rc;
         if (c.colfft) {
             const bool own_rows = own_row_passes(c.g);
             if (own_rows) { StageTimer t(kStageFft, s); if (int rc = launch_row_r2c(c.g, grid, ws + c.off_col, c.chunk_planes, np, spec, s)) return rc; }
@@ -617,6 +629,17 @@ int nfft_hip_adjoint(const nfft_hip_problem *p, const float *pos, const void *x,
                      void *stream)
 {
     return adjoint_impl(p, pos, batch, nullptr, x, x_is_complex, real_output, y, workspace, workspace_bytes, stream);
+}
+
+int nfft_hip_adjoint_build_plan(const nfft_hip_problem *p, const float *pos, const int64_t *batch, void *plan,
+                                int64_t plan_bytes, const void *x, int x_is_complex, int real_output, void *y,
+                                void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (int rc = validate(p)) return rc;
+    if (!plan || plan_bytes < plan_set(p).total) { set_error("plan buffer too small"); return NFFT_HIP_EWORKSPACE; }
+    if (p->num_points > 0 && !pos) { set_error("Input mismatch: pos is null"); return NFFT_HIP_EINVAL; }
+    return adjoint_impl(p, pos, batch, nullptr, x, x_is_complex, real_output, y, workspace, workspace_bytes, stream,
+                        nullptr, 0, plan);
 }
 
 int nfft_hip_forward(const nfft_hip_problem *p, const float *pos, const void *xhat, int x_is_complex,

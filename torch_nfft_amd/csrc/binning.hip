@@ -35,7 +35,7 @@ PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)
     L.off_offsets = o; o = align_up(o + (L.ntiles + 1) * 4, 256);
     L.off_cursor = o;  o = align_up(o + (L.ntiles + 1) * 4, 256);
     L.off_perm = o;    o = align_up(o + L.cap * 4, 256);
-    L.off_spos = o;    o = align_up(o + L.cap * g.dim * 4, 256);
+    L.off_spos = o;    o = align_up(o + L.cap * g.pstride * 4, 256);
     L.off_scan = o;    o = align_up(o + L.scan_bytes, 256);
     // scratch of the two-level sort: per-(pencil, block) counts + their scan, and the pencil-ordered records
     L.off_hist = o;    o = align_up(o + (L.two_level ? scan_items * 4 : 0), 256);
@@ -45,10 +45,13 @@ PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)
     L.off_hist2 = o;   o = align_up(o + (L.two_level ? L.npencils * kSort2Parts * (int64_t)g.l1bins * g.SB * g.CG * 4 : 0), 256);
     L.grouped = L.two_level && g.CG == 3;
     L.off_groups = o;  o = align_up(o + (L.grouped ? L.ntiles * 2 * 4 : 0), 256);
+    // launch order of the matrix-core kernels' work items, biggest first (wide tiling; item_order_kernel below)
+    L.off_order = o;   o = align_up(o + (g.wide ? (int64_t)g.nta[1] * g.nta[2] * B * kSegMax * 4 : 0), 256);
     // the count passes leave the keys they computed for the scatter passes (two bytes per point / record instead of
     // two or three more split_cell + tile-index evaluations)
     L.off_key1 = o;    o = align_up(o + (L.two_level && !g.owned ? n * 2 : 0), 256);
     L.off_key2 = o;    o = align_up(o + (L.two_level ? L.cap * 2 : 0), 256);
+    L.off_tmpx = o;    o = align_up(o + (L.two_level && g.dim == 3 ? L.cap * 4 : 0), 256);
     L.total = o;
     return L;
 }
@@ -89,7 +92,8 @@ __global__ void __launch_bounds__(256) bin_count_kernel(Geom g, const float *__r
 __global__ void __launch_bounds__(256) bin_fill_kernel(Geom g, const float *__restrict__ pos,
                                                       const int64_t *__restrict__ batch, int64_t n, int64_t B,
                                                       const int *__restrict__ offsets, int *__restrict__ cursor,
-                                                      int *__restrict__ perm, float *__restrict__ spos)
+                                                      int *__restrict__ perm, float *__restrict__ spos,
+                                                      const float *__restrict__ x)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int tiles[4];
@@ -97,7 +101,8 @@ __global__ void __launch_bounds__(256) bin_fill_kernel(Geom g, const float *__re
         for (int q = 0; q < k; ++q) {
             const int slot = offsets[tiles[q]] + atomicAdd(&cursor[tiles[q]], 1);
             perm[slot] = (int)i;
-            for (int u = 0; u < g.dim; ++u) spos[(int64_t)slot * g.dim + u] = pos[i * g.dim + u];
+            for (int u = 0; u < g.dim; ++u) spos[(int64_t)slot * g.pstride + u] = pos[i * g.dim + u];
+            if (g.dim == 3) spos[(int64_t)slot * 4 + 3] = x ? x[i] : 0.0f;
         }
     }
 }
@@ -207,7 +212,8 @@ sort1_count_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restr
 __global__ void __launch_bounds__(kSortThreads)
 sort1_scatter_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restrict__ batch, int64_t n, int64_t B,
                      int npencils, int nblocks, const int *__restrict__ hscan, const unsigned short *__restrict__ key1,
-                     float4 *__restrict__ tmp)
+                     float4 *__restrict__ tmp, const float *__restrict__ x /* optional: one coefficient per point ... */,
+                     float *__restrict__ tmpx /* ... which travels next to the point's record */)
 {
     extern __shared__ int lds_cur[];
     for (int i = threadIdx.x; i < npencils; i += kSortThreads) lds_cur[i] = hscan[(int64_t)i * nblocks + blockIdx.x];
@@ -215,7 +221,7 @@ sort1_scatter_kernel(Geom g, const float *__restrict__ pos, const int64_t *__res
     const int64_t lo = (int64_t)blockIdx.x * kSortBlockPoints;
     const int64_t hi = min(n, lo + kSortBlockPoints);
     for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)kSortThreads * kSortUnroll) {
-        float c0[kSortUnroll], c1[kSortUnroll], c2[kSortUnroll];
+        float c0[kSortUnroll], c1[kSortUnroll], c2[kSortUnroll], xx[kSortUnroll];
         int64_t bb[kSortUnroll];
         int kk[kSortUnroll];
 #pragma unroll
@@ -225,6 +231,7 @@ sort1_scatter_kernel(Geom g, const float *__restrict__ pos, const int64_t *__res
             load_point(pos, g.dim, i, live, c0[q], c1[q], c2[q]);
             bb[q] = live && batch && g.owned ? batch[i] : 0;
             kk[q] = live && !g.owned ? key1[i] : 0;
+            xx[q] = live && x ? x[i] : 0.0f;
         }
 #pragma unroll
         for (int q = 0; q < kSortUnroll; ++q) {
@@ -241,6 +248,7 @@ sort1_scatter_kernel(Geom g, const float *__restrict__ pos, const int64_t *__res
             for (int r = 0; r < k; ++r) {
                 const int slot = atomicAdd(&lds_cur[bins[r]], 1);
                 tmp[slot] = make_float4(c0[q], c1[q], c2[q], __int_as_float((int)i));
+                if (x) tmpx[slot] = xx[q];
             }
         }
     }
@@ -320,7 +328,8 @@ sort2_count_kernel(Geom g, int nblocks, const int *__restrict__ hscan, const flo
 __global__ void __launch_bounds__(kSortThreads)
 sort2_scatter_kernel(Geom g, int npencils, int nblocks, const int *__restrict__ hscan, const float4 *__restrict__ tmp,
                      const int *__restrict__ hist2, const unsigned short *__restrict__ key2, int *__restrict__ offsets,
-                     int *__restrict__ groups, int *__restrict__ perm, float *__restrict__ spos)
+                     int *__restrict__ groups, int *__restrict__ perm, float *__restrict__ spos,
+                     const float *__restrict__ tmpx /* nullptr: the plan carries no coefficients (fourth float = 0) */)
 {
     extern __shared__ int lds2[];  // [fine keys] this part's cursors, [fine keys] totals over the parts
     const int l1 = blockIdx.x, part = blockIdx.y;
@@ -375,11 +384,13 @@ sort2_scatter_kernel(Geom g, int npencils, int nblocks, const int *__restrict__ 
     for (int j0 = r0 + threadIdx.x; j0 < r1; j0 += kSortThreads * 8) {
         float4 recs[8];
         int keys[8];
+        float xv[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int j = j0 + q * kSortThreads;
             recs[q] = j < r1 ? tmp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
             keys[q] = j < r1 ? key2[j] : 0;  // (left by the count pass)
+            xv[q] = j < r1 && tmpx ? tmpx[j] : 0.0f;
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -388,10 +399,8 @@ sort2_scatter_kernel(Geom g, int npencils, int nblocks, const int *__restrict__ 
             const int slot = atomicAdd(&lds2[keys[q]], 1);
             perm[slot] = __float_as_int(rec.w);
             if (g.dim == 3) {
-                // one 12-byte store instead of three 4-byte ones (the pass is bound by scattered store requests)
-                typedef float f32x3 __attribute__((ext_vector_type(3)));
-                f32x3 v = {rec.x, rec.y, rec.z};
-                __builtin_memcpy(spos + (int64_t)slot * 3, &v, 12);
+                // one aligned 16-byte store {p0, p1, p2, x} (the pass is bound by scattered store requests, not bytes)
+                ((float4 *)spos)[slot] = make_float4(rec.x, rec.y, rec.z, xv[q]);
             } else {
                 spos[(int64_t)slot * g.dim] = rec.x;
                 if (g.dim > 1) spos[(int64_t)slot * g.dim + 1] = rec.y;
@@ -435,6 +444,60 @@ segment_split_kernel(Geom g, int npl /* point sets x pencils */, int runs, int t
         if (p == 1) first_end[(int64_t)pl * kSegMax + r] = end;
         else overflow[1 + slot + (p - 2)] = make_int4(pl, prev, end, 0);
         prev = end;
+    }
+}
+
+// Launch order of the work items of one point set, biggest first: the kernels take item order[blockIdx.x] instead of
+// item blockIdx.x.  Workgroups are dispatched in index order, one per CU (LDS-bound), ~5.4 per CU: with the pencils in
+// grid order the last workgroups to start are as big as any and the launch ends with a quarter of the CUs idle
+// (measured at config C3: 90 % CU utilisation; edge pencils hold 6/23 or 17/55 of a full pencil's points).  Longest
+// first, the tail is made of the small items.  Counting sort into 1024 size classes; one workgroup per point set.
+__global__ void __launch_bounds__(1024)
+item_order_kernel(Geom g, int pencils, int runs, const int *__restrict__ offsets, const int *__restrict__ first_end,
+                  int *__restrict__ order /* [set][pencils * runs] */)
+{
+    __shared__ int cls[1024 + 1];
+    __shared__ int maxpts;
+    const int b = blockIdx.x;
+    const int nitems = pencils * runs;
+    const int seg_slabs = (g.M + runs - 1) / runs;
+    auto points = [&](const int it) {
+        const int pencil = it / runs, seg = it - pencil * runs;
+        const int sb = min(seg * seg_slabs, g.M);
+        if (sb >= g.M) return 0;
+        const int64_t pl = (int64_t)b * pencils + pencil;
+        const int *off = offsets + pl * g.np0;
+        return off[first_end[pl * kSegMax + seg]] - off[sb];
+    };
+    for (int i = threadIdx.x; i <= 1024; i += 1024) cls[i] = 0;
+    if (threadIdx.x == 0) maxpts = 1;
+    __syncthreads();
+    int mx = 0;
+    for (int it = threadIdx.x; it < nitems; it += 1024) mx = max(mx, points(it));
+    atomicMax(&maxpts, mx);
+    __syncthreads();
+    const float scale = 1023.0f / (float)maxpts;
+    auto size_class = [&](const int pts) { return 1023 - min(1023, (int)((float)pts * scale)); };  // 0 = biggest
+    for (int it = threadIdx.x; it < nitems; it += 1024) atomicAdd(&cls[size_class(points(it)) + 1], 1);
+    __syncthreads();
+    if (threadIdx.x < 64) {  // inclusive scan of the 1024 class counts -> first slot of every class
+        int carry = 0;
+        for (int base = 1; base <= 1024; base += 64) {
+            const int v = cls[base + threadIdx.x];
+            int incl = v;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off);
+                if ((int)threadIdx.x >= off) incl += t;
+            }
+            cls[base + threadIdx.x] = carry + incl;
+            carry += __shfl(incl, 63);
+        }
+    }
+    __syncthreads();
+    // cls[c] = items in classes before c (cls[0] = 0): cursors
+    for (int it = threadIdx.x; it < nitems; it += 1024) {
+        const int slot = atomicAdd(&cls[size_class(points(it))], 1);
+        order[(int64_t)b * nitems + slot] = it;
     }
 }
 
@@ -485,7 +548,7 @@ static inline int grid_for(int64_t work, int block)
 }
 
 static void launch_segment_split(const Geom &g, int64_t n, int64_t B, const int *offsets, int *first_end,
-                                 int4 *overflow, int capacity, hipStream_t stream)
+                                 int4 *overflow, int capacity, int *order, hipStream_t stream)
 {
     const int64_t pencils = (int64_t)g.nta[1] * g.nta[2], npl = pencils * B;
     const int ncu = device_cu_count();
@@ -494,11 +557,15 @@ static void launch_segment_split(const Geom &g, int64_t n, int64_t B, const int 
     if (npl > 0)
         hipLaunchKernelGGL(segment_split_kernel, dim3((unsigned)npl), dim3(64), 0, stream, g, (int)npl, runs, target,
                            offsets, first_end, overflow, capacity);
+    if (npl > 0)
+        hipLaunchKernelGGL(item_order_kernel, dim3((unsigned)B), dim3(1024), 0, stream, g, (int)pencils, runs, offsets,
+                           first_end, order);
 }
 
 int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, const int64_t *batch, int64_t n, int64_t B,
-                       void *plan, hipStream_t stream)
+                       void *plan, hipStream_t stream, const float *x)
 {
+    if (g.dim != 3) x = nullptr;  // (only the 16-byte records of 3-D plans have room for a coefficient)
     char *base = (char *)plan;
     int *offsets = (int *)(base + L.off_offsets);
     int *cursor = (int *)(base + L.off_cursor);
@@ -519,17 +586,19 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
         if ((int64_t)scan_bytes > L.scan_bytes) { set_error("scan scratch too small"); return 2; }
         NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(base + L.off_scan, scan_bytes, hist, hscan, (int)items, stream));
         hipLaunchKernelGGL(sort1_scatter_kernel, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
-                           npencils, nblocks, hscan, key1, tmp);
+                           npencils, nblocks, hscan, key1, tmp, x, (float *)(base + L.off_tmpx));
         int *hist2 = (int *)(base + L.off_hist2);
         const size_t lds2 = (size_t)g.l1bins * g.SB * g.CG * 4;
         hipLaunchKernelGGL(sort2_count_kernel, dim3(npencils, kSort2Parts), dim3(kSortThreads), lds2, stream, g, nblocks,
                            hscan, tmp, hist2, key2);
         hipLaunchKernelGGL(sort2_scatter_kernel, dim3(npencils, kSort2Parts), dim3(kSortThreads), 2 * lds2, stream, g,
-                           npencils, nblocks, hscan, tmp, hist2, key2, offsets, (int *)(base + L.off_groups), perm, spos);
+                           npencils, nblocks, hscan, tmp, hist2, key2, offsets, (int *)(base + L.off_groups), perm, spos,
+                           x ? (const float *)(base + L.off_tmpx) : nullptr);
         if (g.wide) {
             // the record area is free now: it holds the overflow list of the load-balance split
             NFFT_HIP_CHECK(hipMemsetAsync(tmp, 0, 16, stream));
-            launch_segment_split(g, n, B, offsets, cursor, (int4 *)tmp, (int)std::min<int64_t>(n - 1, 1 << 28), stream);
+            launch_segment_split(g, n, B, offsets, cursor, (int4 *)tmp, (int)std::min<int64_t>(n - 1, 1 << 28),
+                                 (int *)(base + L.off_order), stream);
         }
         NFFT_HIP_CHECK(hipGetLastError());
         return 0;
@@ -548,10 +617,10 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
     NFFT_HIP_CHECK(hipMemsetAsync(cursor, 0, (L.ntiles + 1) * 4, stream));
     if (n > 0) {
         hipLaunchKernelGGL(bin_fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, g, pos, batch, n, B, offsets,
-                           cursor, perm, spos);
+                           cursor, perm, spos, x);
     }
     // (no record area in this path: ranges stay whole; the cursors are no longer needed)
-    if (g.wide) launch_segment_split(g, n, B, offsets, cursor, nullptr, 0, stream);
+    if (g.wide) launch_segment_split(g, n, B, offsets, cursor, nullptr, 0, (int *)(base + L.off_order), stream);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -103,6 +103,10 @@ struct Geom {
     // or gather block of one group needs two of the tile's four 16-column k-steps / one of its two 32-column halves:
     // the matrix-core kernels skip the rest.  tile_offsets keeps one entry per slab.
     int CG;
+    // floats per point of the plan's tile-ordered copy: 3-D points are 16-byte records {p0, p1, p2, x} -- the fourth float
+    // carries the point's (single, real) coefficient when the plan is built inside an adjoint call (binning.hip), else 0 --
+    // so that every consumer loads a point with one aligned 16-byte access; 1-D / 2-D keep dim floats
+    int pstride;
     int64_t cells; // M^dim
 };
 
@@ -150,6 +154,7 @@ inline Geom make_geom(int dim, int64_t N, int64_t m, bool owned = false)
     g.sb2 = sub ? g.Ta[2] / kSub : 1;
     g.SB = g.sb1 * g.sb2;
     g.CG = (g.wide && !g.owned && g.SB == 1 && column_groups_enabled()) ? 3 : 1;
+    g.pstride = dim == 3 ? 4 : dim;
     return g;
 }
 
@@ -295,7 +300,7 @@ __device__ __forceinline__ int sub_of_cells(const Geom &g, const int cell[3])
 #endif // __HIPCC__
 
 // ---- plan layout -----------------------------------------------------------
-// [ tile_offset int32[ntiles*SB+1] | cursor int32[ntiles] | perm int32[n] | spos float[n*dim] | scan temp | sort scratch ]
+// [ tile_offset int32[ntiles*SB+1] | cursor int32[ntiles] | perm int32[n] | spos float[n*pstride] | scan temp | sort scratch ]
 // Wide tiling, load balance of the matrix-core kernels: a pencil is swept in `runs` equal ranges of slabs (one
 // workgroup each, as many as give ~5.4 workgroups per CU for an average pencil).  Ranges that hold far more points
 // than average (clustered inputs) are cut further by point count at plan time: the workgroup of the range keeps the
@@ -342,7 +347,9 @@ struct PlanLayout {
     int64_t off_offsets, off_cursor, off_perm, off_spos, off_scan, scan_bytes;
     int64_t off_hist, off_hscan, off_tmp, off_hist2;
     int64_t off_groups;  // column-group starts (two ints per plan bin) when `grouped`
+    int64_t off_order;   // wide tiling: work items of every point set in launch order, biggest first (binning.hip)
     int64_t off_key1, off_key2;  // sort scratch: first-level bin of every point, fine key of every record (16 bits each)
+    int64_t off_tmpx;            // sort scratch: the coefficient that travels with a first-level record (plans built with x)
     bool grouped;        // the plan is ordered by column group inside the slabs (Geom::CG == 3, two-level sort)
     int64_t total;
 };

@@ -141,62 +141,94 @@ struct PlanCache {
 // the HIP runtime have been torn down)
 PlanCache &g_cache = *new PlanCache;
 
-at::Tensor get_plan(const Points &p, const nfft_hip_problem &q)
+// Cache key of a point set, or std::nullopt-like `cacheable == false` for points the cache must not hold.
+struct PlanLookup {
+    PlanKey key;
+    bool use_cache = false;
+    void *stream = nullptr;
+};
+
+PlanLookup plan_lookup_key(const Points &p, const nfft_hip_problem &q)
 {
-    void *stream = stream_of(p.pos);
+    PlanLookup lk;
+    lk.stream = stream_of(p.pos);
     // Inference tensors carry no version counter (Tensor::_version() throws): such points are planned afresh in
     // every call and never enter the cache -- an in-place edit could not be told from the cached state.
     const bool cacheable = !p.pos.is_inference() && !(p.batch.defined() && p.batch.is_inference());
-    PlanKey key;
+    PlanKey &key = lk.key;
     key.pos_ptr = p.pos.data_ptr();
     key.batch_ptr = p.batch.defined() ? p.batch.data_ptr() : nullptr;
     key.n = p.n; key.B = p.B; key.N = q.N; key.m = q.m; key.dim = p.dim; key.device = p.pos.device().index();
     key.flags = q.flags;
-    std::lock_guard<std::mutex> lock(g_cache.mutex);
-    const bool use_cache = g_cache.enabled && cacheable;
-    if (use_cache) {
+    lk.use_cache = g_cache.enabled && cacheable;  // (read under the lock by the callers below)
+    if (lk.use_cache) {
         key.pos_version = (int64_t)p.pos._version();
         key.batch_version = p.batch.defined() ? (int64_t)p.batch._version() : -1;
     }
-    if (use_cache) {
-        for (PlanEntry &e : g_cache.entries) {
-            if (e.plan.defined() && e.key == key) {
-                ++g_cache.hits;
-                e.last_use = ++g_cache.tick;
-                if (e.stream != stream) {
-                    TORCH_CHECK(hipStreamWaitEvent((hipStream_t)stream, e.built, 0) == hipSuccess,
-                                "hipStreamWaitEvent failed");
-                    e.plan.record_stream(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(key.device));
-                }
-                return e.plan;
+    return lk;
+}
+
+// a cached plan for these points, made safe to use on the caller's stream; undefined tensor on a miss (lock held)
+at::Tensor cache_find(const PlanLookup &lk)
+{
+    if (!lk.use_cache) return at::Tensor();
+    for (PlanEntry &e : g_cache.entries) {
+        if (e.plan.defined() && e.key == lk.key) {
+            ++g_cache.hits;
+            e.last_use = ++g_cache.tick;
+            if (e.stream != lk.stream) {
+                TORCH_CHECK(hipStreamWaitEvent((hipStream_t)lk.stream, e.built, 0) == hipSuccess,
+                            "hipStreamWaitEvent failed");
+                e.plan.record_stream(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(lk.key.device));
             }
+            return e.plan;
         }
     }
-    ++g_cache.misses;
-    const int64_t nbytes = nfft_hip_plan_bytes(&q);
+    return at::Tensor();
+}
+
+// enter a plan that has just been enqueued on lk.stream (lock held)
+void cache_insert(const PlanLookup &lk, const Points &p, const at::Tensor &plan)
+{
+    if (!lk.use_cache) return;
+    PlanEntry *slot = &g_cache.entries[0];
+    if (g_cache.entries[0].plan.defined() &&
+        (!g_cache.entries[1].plan.defined() || g_cache.entries[1].last_use < g_cache.entries[0].last_use))
+        slot = &g_cache.entries[1];
+    if (slot->built && slot->key.device != lk.key.device) {  // events belong to the device they were created on
+        (void)hipEventDestroy(slot->built);
+        slot->built = nullptr;
+    }
+    if (!slot->built)
+        TORCH_CHECK(hipEventCreateWithFlags(&slot->built, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+    TORCH_CHECK(hipEventRecord(slot->built, (hipStream_t)lk.stream) == hipSuccess, "hipEventRecord failed");
+    slot->key = lk.key;
+    slot->plan = plan;
+    slot->pos = p.pos;
+    slot->batch = p.batch;
+    slot->stream = lk.stream;
+    slot->last_use = ++g_cache.tick;
+}
+
+at::Tensor new_plan_buffer(const Points &p, const nfft_hip_problem &q, int64_t &nbytes)
+{
+    nbytes = nfft_hip_plan_bytes(&q);
     if (nbytes < 0) check_rc(NFFT_HIP_EINVAL);
-    at::Tensor plan = byte_buffer(nbytes, p.pos);
+    return byte_buffer(nbytes, p.pos);
+}
+
+at::Tensor get_plan(const Points &p, const nfft_hip_problem &q)
+{
+    std::lock_guard<std::mutex> lock(g_cache.mutex);
+    const PlanLookup lk = plan_lookup_key(p, q);
+    at::Tensor plan = cache_find(lk);
+    if (plan.defined()) return plan;
+    ++g_cache.misses;
+    int64_t nbytes = 0;
+    plan = new_plan_buffer(p, q, nbytes);
     check_rc(nfft_hip_plan_points(&q, p.pos.data_ptr<float>(), p.batch.defined() ? p.batch.data_ptr<int64_t>() : nullptr,
-                                  plan.data_ptr(), nbytes, stream));
-    if (use_cache) {
-        PlanEntry *slot = &g_cache.entries[0];
-        if (g_cache.entries[0].plan.defined() &&
-            (!g_cache.entries[1].plan.defined() || g_cache.entries[1].last_use < g_cache.entries[0].last_use))
-            slot = &g_cache.entries[1];
-        if (slot->built && slot->key.device != key.device) {  // events belong to the device they were created on
-            (void)hipEventDestroy(slot->built);
-            slot->built = nullptr;
-        }
-        if (!slot->built)
-            TORCH_CHECK(hipEventCreateWithFlags(&slot->built, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
-        TORCH_CHECK(hipEventRecord(slot->built, (hipStream_t)stream) == hipSuccess, "hipEventRecord failed");
-        slot->key = key;
-        slot->plan = plan;
-        slot->pos = p.pos;
-        slot->batch = p.batch;
-        slot->stream = stream;
-        slot->last_use = ++g_cache.tick;
-    }
+                                  plan.data_ptr(), nbytes, lk.stream));
+    cache_insert(lk, p, plan);
     return plan;
 }
 
@@ -249,9 +281,28 @@ at::Tensor nfft_adjoint(at::Tensor pos, at::Tensor x, c10::optional<at::Tensor> 
     const int64_t ws_bytes = nfft_hip_adjoint_workspace_bytes(&q, real_input ? 0 : 1, real_output ? 1 : 0);
     if (ws_bytes < 0) check_rc(std::string(nfft_hip_last_error()).rfind("Input mismatch", 0) == 0 ? NFFT_HIP_EINVAL : NFFT_HIP_EFFT);
     at::Tensor ws = byte_buffer(ws_bytes, x);
-    const at::Tensor plan = get_plan(p, q);
-    check_rc(nfft_hip_adjoint_planned(&q, plan.data_ptr(), xc.data_ptr(), real_input ? 0 : 1, real_output ? 1 : 0,
-                                      y.data_ptr(), ws.data_ptr(), ws_bytes, stream_of(x)));
+    {
+        // cached plan: the planned entry; miss: the adjoint builds the plan itself (the coefficients ride through the
+        // plan's sort, nfft_hip_adjoint_build_plan) and the plan goes into the cache for the calls that follow
+        std::unique_lock<std::mutex> lock(g_cache.mutex);
+        const PlanLookup lk = plan_lookup_key(p, q);
+        at::Tensor plan = cache_find(lk);
+        if (!plan.defined() && lk.stream == stream_of(x)) {
+            ++g_cache.misses;
+            int64_t nbytes = 0;
+            plan = new_plan_buffer(p, q, nbytes);
+            check_rc(nfft_hip_adjoint_build_plan(&q, p.pos.data_ptr<float>(),
+                                                 p.batch.defined() ? p.batch.data_ptr<int64_t>() : nullptr, plan.data_ptr(),
+                                                 nbytes, xc.data_ptr(), real_input ? 0 : 1, real_output ? 1 : 0, y.data_ptr(),
+                                                 ws.data_ptr(), ws_bytes, lk.stream));
+            cache_insert(lk, p, plan);
+            return y;
+        }
+        lock.unlock();
+        if (!plan.defined()) plan = get_plan(p, q);
+        check_rc(nfft_hip_adjoint_planned(&q, plan.data_ptr(), xc.data_ptr(), real_input ? 0 : 1, real_output ? 1 : 0,
+                                          y.data_ptr(), ws.data_ptr(), ws_bytes, stream_of(x)));
+    }
     return y;
 }
 

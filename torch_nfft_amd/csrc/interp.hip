@@ -130,9 +130,10 @@ interp_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__r
             int c0 = 0, c1 = 0, c2 = 0;
             float f0 = 0.f, f1 = 0.f, f2 = 0.f;
             if (DIM == 3) {
-                split_cell(spos[(int64_t)j * 3 + 0], g.M, c0, f0);
-                split_cell(spos[(int64_t)j * 3 + 1], g.M, c1, f1);
-                split_cell(spos[(int64_t)j * 3 + 2], g.M, c2, f2);
+                const f32x4 rec = *(const f32x4 *)(spos + (int64_t)j * 4);  // plan record {p0, p1, p2, x}
+                split_cell(rec.x, g.M, c0, f0);
+                split_cell(rec.y, g.M, c1, f1);
+                split_cell(rec.z, g.M, c2, f2);
             } else if (DIM == 2) {
                 split_cell(spos[(int64_t)j * 2 + 0], g.M, c1, f1);
                 split_cell(spos[(int64_t)j * 2 + 1], g.M, c2, f2);

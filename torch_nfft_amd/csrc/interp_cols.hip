@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(kIcThreads) __attribute__((amdgpu_waves_per_eu
 interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__restrict__ perm,
                    const float *__restrict__ spos, const float *__restrict__ grid, const int Cr, const int64_t plane0,
                    const int64_t nplanes, const int64_t group0, float *__restrict__ yr, const int seg_slabs,
-                   const int nsegm, const int *__restrict__ first_end, const int4 *__restrict__ overflow)
+                   const int nsegm, const int *__restrict__ first_end, const int *__restrict__ order, const int4 *__restrict__ overflow)
 {
     constexpr int m = W / 2 - 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -92,8 +92,10 @@ interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
         sb = it.y;
         se = it.z;
     } else {
-        pencil = blockIdx.x / nsegm;
-        const int seg = blockIdx.x % nsegm;
+        // (items in the plan's launch order, biggest first: the tail of the launch is made of the small ones)
+        const int bx = order[(int64_t)b * gridDim.x + blockIdx.x];
+        pencil = bx / nsegm;
+        const int seg = bx - pencil * nsegm;
         sb = min(seg * seg_slabs, M);
         se = sb < M ? first_end[(int64_t)(b * pencils + pencil) * kSegMax + seg] : sb;
     }
@@ -151,9 +153,10 @@ interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
             int c0 = 0, c1 = 0, c2 = 0;
             float f0 = 0.f, f1 = 0.f, f2 = 0.f;
             if (valid) {
-                split_cell(spos[(int64_t)pt * 3 + 0], M, c0, f0);
-                split_cell(spos[(int64_t)pt * 3 + 1], M, c1, f1);
-                split_cell(spos[(int64_t)pt * 3 + 2], M, c2, f2);
+                const f32x4 rec = *(const f32x4 *)(spos + (int64_t)pt * 4);  // plan record {p0, p1, p2, x}
+                split_cell(rec.x, M, c0, f0);
+                split_cell(rec.y, M, c1, f1);
+                split_cell(rec.z, M, c2, f2);
             }
             const int nvalid = min(32, p_end - (c_begin + 32 * j));
             const int zf = __builtin_amdgcn_readlane(c0, 0) - m;
@@ -325,6 +328,7 @@ static int launch_ic_t(const Geom &g, const PlanLayout &L, const void *plan, con
     const int *perm = (const int *)(base + L.off_perm);
     const float *spos = (const float *)(base + L.off_spos);
     const int *first_end = (const int *)(base + L.off_cursor);
+    const int *order = (const int *)(base + L.off_order);
     const int64_t pencils = (int64_t)g.nta[1] * g.nta[2];
     int64_t nsets = g.tiles_per_batch > 0 ? L.ntiles / g.tiles_per_batch : 1;
     if (nsets < 1) nsets = 1;
@@ -345,12 +349,12 @@ static int launch_ic_t(const Geom &g, const PlanLayout &L, const void *plan, con
     }
     const dim3 blocks((unsigned)(pencils * nsegm), (unsigned)ngroups);
     hipLaunchKernelGGL((interp_cols_kernel<W, false>), blocks, dim3(kIcThreads), sizeof(IcLds), stream, g, to, perm, spos,
-                       grid, (int)Cr, plane0, nplanes, group0, yr, seg_slabs, nsegm, first_end, (const int4 *)nullptr);
+                       grid, (int)Cr, plane0, nplanes, group0, yr, seg_slabs, nsegm, first_end, order, (const int4 *)nullptr);
     if (L.two_level) {
         const int4 *overflow = (const int4 *)(base + L.off_tmp);
         const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)ngroups);
         hipLaunchKernelGGL((interp_cols_kernel<W, true>), oblocks, dim3(kIcThreads), sizeof(IcLds), stream, g, to, perm,
-                           spos, grid, (int)Cr, plane0, nplanes, group0, yr, seg_slabs, nsegm, first_end, overflow);
+                           spos, grid, (int)Cr, plane0, nplanes, group0, yr, seg_slabs, nsegm, first_end, order, overflow);
     }
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;

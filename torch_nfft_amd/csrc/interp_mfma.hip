@@ -39,7 +39,7 @@ template <int W, bool OVERFLOW>
 __global__ void __launch_bounds__(kGmThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__restrict__ perm,
                    const float *__restrict__ spos, const float *__restrict__ grid, const int Cr, const int plane0,
-                   float *__restrict__ yr, const int seg_slabs, const int nsegm, const int *__restrict__ first_end,
+                   float *__restrict__ yr, const int seg_slabs, const int nsegm, const int *__restrict__ first_end, const int *__restrict__ order,
                    const int4 *__restrict__ overflow)
 {
     constexpr int m = W / 2 - 1;
@@ -72,8 +72,10 @@ interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
         sb = it.y;
         se = it.z;
     } else {
-        pencil = blockIdx.x / nsegm;
-        const int seg = blockIdx.x % nsegm;
+        // (items in the plan's launch order, biggest first: the tail of the launch is made of the small ones)
+        const int bx = order[(int64_t)b * gridDim.x + blockIdx.x];
+        pencil = bx / nsegm;
+        const int seg = bx - pencil * nsegm;
         sb = min(seg * seg_slabs, g.M);
         se = sb < g.M ? first_end[(int64_t)(b * pencils + pencil) * kSegMax + seg] : sb;
     }
@@ -184,9 +186,10 @@ interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
             int c0 = 0, c1 = 0, c2 = 0;
             float f0 = 0.f, f1 = 0.f, f2 = 0.f;
             if (valid) {
-                split_cell(spos[(int64_t)j * 3 + 0], M, c0, f0);
-                split_cell(spos[(int64_t)j * 3 + 1], M, c1, f1);
-                split_cell(spos[(int64_t)j * 3 + 2], M, c2, f2);
+                const f32x4 rec = *(const f32x4 *)(spos + (int64_t)j * 4);  // plan record {p0, p1, p2, x}
+                split_cell(rec.x, M, c0, f0);
+                split_cell(rec.y, M, c1, f1);
+                split_cell(rec.z, M, c2, f2);
             }
             // the plan is sorted by slab: the block's planes run from the first point's window to the last one's
             const int nvalid = min(32, e - j0);
@@ -282,13 +285,14 @@ static int launch_gm_t(const Geom &g, const PlanLayout &L, const void *plan, con
     }
     const char *base = (const char *)plan;
     const int *first_end = (const int *)(base + L.off_cursor);
+    const int *order = (const int *)(base + L.off_order);
     hipLaunchKernelGGL((interp_mfma_kernel<W, false>), blocks, dim3(kGmThreads), sizeof(GatherMfmaLds), stream, g, to,
-                       perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, (const int4 *)nullptr);
+                       perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, order, (const int4 *)nullptr);
     if (L.two_level) {
         const int4 *overflow = (const int4 *)(base + L.off_tmp);
         const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
         hipLaunchKernelGGL((interp_mfma_kernel<W, true>), oblocks, dim3(kGmThreads), sizeof(GatherMfmaLds), stream, g,
-                           to, perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, overflow);
+                           to, perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, order, overflow);
     }
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;

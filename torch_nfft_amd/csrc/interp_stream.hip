@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(kIsThreads) __attribute__((amdgpu_waves_per_eu
 interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__restrict__ group_starts,
                      const int *__restrict__ perm, const float *__restrict__ spos, const float *__restrict__ grid,
                      const int Cr, const int plane0, float *__restrict__ yr, const int seg_slabs, const int nsegm,
-                     const int *__restrict__ first_end, const int4 *__restrict__ overflow, int *__restrict__ status)
+                     const int *__restrict__ first_end, const int *__restrict__ order, const int4 *__restrict__ overflow, int *__restrict__ status)
 {
     constexpr int m = W / 2 - 1;
     constexpr int TC = 17 - W;                                   // slabs per chunk
@@ -111,8 +111,10 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
         sb = it.y;
         se = it.z;
     } else {
-        pencil = blockIdx.x / nsegm;
-        const int seg = blockIdx.x % nsegm;
+        // (items in the plan's launch order, biggest first: the tail of the launch is made of the small ones)
+        const int bx = order[(int64_t)b * gridDim.x + blockIdx.x];
+        pencil = bx / nsegm;
+        const int seg = bx - pencil * nsegm;
         sb = min(seg * seg_slabs, M);
         se = sb < M ? first_end[(int64_t)(b * pencils + pencil) * kSegMax + seg] : sb;
     }
@@ -317,9 +319,7 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
             a0 = a1 = a2 = 0.0f;
             pm = 0;
             if (idx >= 0) {
-                typedef float f32x3 __attribute__((ext_vector_type(3)));
-                f32x3 v;
-                __builtin_memcpy(&v, spos + (int64_t)idx * 3, 12);  // one 12-byte load
+                const f32x4 v = *(const f32x4 *)(spos + (int64_t)idx * 4);  // plan record {p0, p1, p2, x}: one aligned load
                 a0 = v.x; a1 = v.y; a2 = v.z;
                 pm = perm[idx];
             }
@@ -512,6 +512,7 @@ static int launch_is_t(const Geom &g, const PlanLayout &L, const void *plan, con
     const int *perm = (const int *)(base + L.off_perm);
     const float *spos = (const float *)(base + L.off_spos);
     const int *first_end = (const int *)(base + L.off_cursor);
+    const int *order = (const int *)(base + L.off_order);
     const int64_t pencils = (int64_t)g.nta[1] * g.nta[2];
     int64_t nsets = g.tiles_per_batch > 0 ? L.ntiles / g.tiles_per_batch : 1;
     if (nsets < 1) nsets = 1;
@@ -528,12 +529,12 @@ static int launch_is_t(const Geom &g, const PlanLayout &L, const void *plan, con
         attr_done.mark();
     }
     hipLaunchKernelGGL((interp_stream_kernel<W, false, NG>), blocks, dim3(kIsThreads), sizeof(StreamLds), stream, g, to, gs,
-                       perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, (const int4 *)nullptr, status);
+                       perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, order, (const int4 *)nullptr, status);
     if (L.two_level) {
         const int4 *overflow = (const int4 *)(base + L.off_tmp);
         const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
         hipLaunchKernelGGL((interp_stream_kernel<W, true, NG>), oblocks, dim3(kIsThreads), sizeof(StreamLds), stream, g, to,
-                           gs, perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, overflow, status);
+                           gs, perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, order, overflow, status);
     }
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;

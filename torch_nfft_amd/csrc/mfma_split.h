@@ -54,9 +54,20 @@ __device__ __forceinline__ void lds_dma_dword(const float *gsrc, const float *ld
                  : "v"(gsrc), "s"(lds)
                  : "memory");
 }
+// Sixteen bytes per active lane (a plan record {p0, p1, p2, x}): lane l lands at lds_wave_base + 16 l.
+__device__ __forceinline__ void lds_dma_dwordx4(const float *gsrc, const void *lds_wave_base)
+{
+    const unsigned lds = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds)
+                 : "memory");
+}
 __device__ __forceinline__ void wait_lds_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// all but the newest request (4 LDS-DMA instructions) have landed
-__device__ __forceinline__ void wait_lds_dma_but_newest() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+// all but the newest request (2 LDS-DMA instructions: the point record and the coefficient) have landed
+__device__ __forceinline__ void wait_lds_dma_but_newest() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
 // workgroup barrier that leaves global traffic (LDS-DMA, flush atomics) in flight
 __device__ __forceinline__ void barrier_lds_only() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 

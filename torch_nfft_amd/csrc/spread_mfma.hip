@@ -43,6 +43,20 @@
 
 namespace nfft {
 
+#ifdef NFFT_HIP_TRACE
+// Developer instrumentation (variant builds only, scripts/exp_build.sh -DNFFT_HIP_TRACE): eight 64-bit words per
+// workgroup of the primary launch -- 100 MHz real-time stamps at entry / after the max-|x| pass / at the first batch /
+// at the end, the hardware id of the CU, the item's K-block and point counts.
+__device__ unsigned long long *g_spread_trace = nullptr;
+#define NFFT_TRACE(slot, value)                                                                                   \
+    do {                                                                                                          \
+        if (!OVERFLOW && threadIdx.x == 0 && g_spread_trace)                                                      \
+            g_spread_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = (value);                 \
+    } while (0)
+#else
+#define NFFT_TRACE(slot, value) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int kKB = 16;        // points per K-block (the MFMA K dimension; the table builds map lane = 4 * point + tap group: 4 kKB = 64)
@@ -75,7 +89,8 @@ template <int W>
 struct __align__(16) MfmaLds {
     MfmaOps<W> ops[2];
     MfmaStage stag[2];
-    float raw[2][4][kSlots];              // landing zones of the LDS-DMA (batch b uses b & 1): pos0, pos1, pos2, x
+    f32x4 raw[2][kSlots];                 // landing zones of the LDS-DMA (batch b uses b & 1): plan records {p0, p1, p2, x}
+    float rawx[2][kSlots];                // ... and the coefficient out of the plan-ordered column (plans built without x)
     int raw_have[2][kSlots];
     int raw_slab[2][kNKB];
     int task_counter[2];
@@ -88,9 +103,9 @@ template <int W, bool OVERFLOW, bool OWNED>
 __global__ void __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *__restrict__ spos,
                    const int *__restrict__ perm, const float *__restrict__ xr, float *__restrict__ xs,
-                   const int64_t xs_stride, const int Cr,
+                   const int64_t xs_stride, const int Cr, const int x_in_plan,
                    const int plane0, float *__restrict__ grid, const int seg_slabs, const int nsegm,
-                   const int *__restrict__ first_end, const int4 *__restrict__ overflow)
+                   const int *__restrict__ first_end, const int *__restrict__ order, const int4 *__restrict__ overflow)
 {
     constexpr int m = W / 2 - 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -100,6 +115,8 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: keep it in an SGPR
     const int r32 = lane & 31, h = lane >> 5;
+    NFFT_TRACE(0, __builtin_amdgcn_s_memrealtime());
+    NFFT_TRACE(4, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32));
 
     const int plane_local = blockIdx.y;
     const int plane = plane0 + plane_local;
@@ -122,8 +139,10 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
         sb = it.y;
         se = it.z;
     } else {
-        pencil = blockIdx.x / nsegm;
-        const int seg = blockIdx.x % nsegm;
+        // (items in the plan's launch order, biggest first: the tail of the launch is made of the small ones)
+        const int bx = order[(int64_t)b * gridDim.x + blockIdx.x];
+        pencil = bx / nsegm;
+        const int seg = bx - pencil * nsegm;
         sb = min(seg * seg_slabs, g.M);
         se = sb < g.M ? first_end[(int64_t)(b * pencils + pencil) * kSegMax + seg] : sb;
     }
@@ -148,7 +167,10 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     // max |x| over the plan entries [j_begin, j_end), strided over `nthr` threads.  Through the permutation the loads
     // go out eight at a time: a loop of dependent (index, value) pairs is two HBM latencies per point and thread
     auto absmax_range = [&](const int j_begin, const int j_end, const int t, const int nthr, float mx) {
-        if (perm) {
+        if (x_in_plan) {
+            // the plan was built with this call's coefficients: they sit in the fourth float of the records
+            for (int j = j_begin + t; j < j_end; j += nthr) mx = fmaxf(mx, fabsf(spos[(int64_t)j * 4 + 3]));
+        } else if (perm) {
             for (int j0 = j_begin + t; j0 < j_end; j0 += 8 * nthr) {
                 int pj[8];
                 float v[8];
@@ -197,6 +219,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
             xscale = ldexpf(1.0f, e);
         }
     }
+    NFFT_TRACE(1, __builtin_amdgcn_s_memrealtime());
     const float inv_xscale = 1.0f / xscale;
     const float unscale = xscale * norm * (1.0f / (kOpScale * kOpScale));
     float *const gplane = grid + (int64_t)plane_local * g.cells;
@@ -324,7 +347,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
 
     // ---- staging of a batch: thread -> (K-block, point).  The points of batch i + 4 are requested (LDS-DMA into
     // L.raw[i & 1]) while batch i is accumulated and converted to (cell, fraction) form two steps later: under the
-    // atomic traffic of the flushes a load takes longer than one step.  Every request issues exactly four DMA
+    // atomic traffic of the flushes a load takes longer than one step.  Every request issues exactly two DMA
     // instructions per wave (lanes without a point read a dummy address), so that the consumer can wait with a count.
     int cur = 0;  // slab of this thread's previous K-block (K-blocks only move forward)
     // this thread's slot of a batch: plan index of its point (any valid one for a padding slot), whether it has one,
@@ -358,10 +381,8 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     auto issue_dma = [&](const int batch, const int idx, const int have, const int slab, const float *xsrc) {
         const int j = st / kKB, i = st - j * kKB;
         const int buf = batch & 1;
-        lds_dma_dword(spos + (int64_t)idx * 3 + 0, &L.raw[buf][0][(wave - kStageWave0) * 64]);
-        lds_dma_dword(spos + (int64_t)idx * 3 + 1, &L.raw[buf][1][(wave - kStageWave0) * 64]);
-        lds_dma_dword(spos + (int64_t)idx * 3 + 2, &L.raw[buf][2][(wave - kStageWave0) * 64]);
-        lds_dma_dword(xsrc, &L.raw[buf][3][(wave - kStageWave0) * 64]);
+        lds_dma_dwordx4(spos + (int64_t)idx * 4, &L.raw[buf][(wave - kStageWave0) * 64]);
+        lds_dma_dword(xsrc, &L.rawx[buf][(wave - kStageWave0) * 64]);  // (not used when the plan carries x)
         L.raw_have[buf][st] = have;
         if (i == 0) L.raw_slab[buf][j] = slab;
     };
@@ -379,9 +400,10 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
         int c1 = -1000, c2 = -1000;  // padding slots: outside every window
         if (L.raw_have[buf][st]) {
             int c0;
-            split_cell(L.raw[buf][0][st], g.M, c0, f0);
-            split_cell(L.raw[buf][1][st], g.M, c1, f1);
-            split_cell(L.raw[buf][2][st], g.M, c2, f2);
+            const f32x4 rec = L.raw[buf][st];
+            split_cell(rec.x, g.M, c0, f0);
+            split_cell(rec.y, g.M, c1, f1);
+            split_cell(rec.z, g.M, c2, f2);
             if constexpr (OWNED) {
                 // cell relative to the tile, in [-m - 1, T + m): tap l sits at row c1 - m + l1 of the (unpadded) tile
                 c1 -= tb1;
@@ -393,7 +415,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                 c1 -= tb1 - m;  // row of the point's cell inside the padded pencil (tap l1 sits at row c1 - m + l1)
                 c2 -= tb2 - m;
             }
-            xv = L.raw[buf][3][st] * inv_xscale;
+            xv = (x_in_plan ? rec.w : L.rawx[buf][st]) * inv_xscale;
         }
         S.f0[st] = f0; S.f1[st] = f1; S.f2[st] = f2; S.x[st] = xv;
         S.c1[st] = c1; S.c2[st] = c2;
@@ -559,6 +581,8 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
         stage_request(2);
     }
     __syncthreads();
+    NFFT_TRACE(2, __builtin_amdgcn_s_memrealtime());
+    NFFT_TRACE(5, (unsigned long long)(unsigned)total | ((unsigned long long)(unsigned)(tile_offsets[bin0 + wrap(s_lo + nslab - 1, g.M) + 1] - tile_offsets[bin0 + wrap(s_lo, g.M)]) << 32));
     for (int i = -1; i < nbatch; ++i) {
         if (stager) {
             if (i + 2 < nbatch) stage_convert(L.stag[i & 1], i + 2, true);
@@ -573,11 +597,13 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     }
     // the dummy requests of the last steps must have landed before the workgroup gives its LDS back
     if (stager) wait_lds_dma();
+    NFFT_TRACE(6, __builtin_amdgcn_s_memrealtime());
     flush();
     if constexpr (OWNED) {
         // owned planes behind the last slab that holds points
         for (myz += NOWN; myz < se; myz += NOWN) flush();
     }
+    NFFT_TRACE(3, __builtin_amdgcn_s_memrealtime());
     }  // work items
 }
 
@@ -585,9 +611,16 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
 
 bool spread_mfma_supported(const Geom &g) { return g.dim == 3 && g.wide; }
 
+#ifdef NFFT_HIP_TRACE
+extern "C" int nfft_dbg_set_spread_trace(void *device_buffer)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_spread_trace), &device_buffer, sizeof(device_buffer));
+}
+#endif
+
 template <int W, bool OWNED>
 static int launch_mfma_t(const Geom &g, const PlanLayout &L, const void *plan, const int *to, const float *spos,
-                         const int *perm, const float *xr, float *xs, int64_t n, int64_t Cr, int64_t plane0,
+                         const int *perm, const float *xr, float *xs, bool x_in_plan, int64_t n, int64_t Cr, int64_t plane0,
                          int64_t nplanes, float *grid, hipStream_t stream)
 {
     // Ranges per pencil: about 5-6 workgroups per CU balance the tail of the launch against the 2m+1 halo planes
@@ -609,35 +642,36 @@ static int launch_mfma_t(const Geom &g, const PlanLayout &L, const void *plan, c
     }
     const char *base = (const char *)plan;
     const int *first_end = (const int *)(base + L.off_cursor);
+    const int *order = (const int *)(base + L.off_order);
     hipLaunchKernelGGL((spread_mfma_kernel<W, false, OWNED>), blocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to,
-                       spos, perm, xr, xs, L.cap, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, (const int4 *)nullptr);
+                       spos, perm, xr, xs, L.cap, (int)Cr, x_in_plan ? 1 : 0, (int)plane0, grid, seg_slabs, nsegm, first_end, order, (const int4 *)nullptr);
     if (L.two_level) {
         // the pieces the plan cut off dense ranges (none for uniform inputs: the workgroups then leave at once)
         const int4 *overflow = (const int4 *)(base + L.off_tmp);
         const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
         hipLaunchKernelGGL((spread_mfma_kernel<W, true, OWNED>), oblocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g,
-                           to, spos, perm, xr, xs, L.cap, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, overflow);
+                           to, spos, perm, xr, xs, L.cap, (int)Cr, x_in_plan ? 1 : 0, (int)plane0, grid, seg_slabs, nsegm, first_end, order, overflow);
     }
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 template <bool OWNED>
-static int launch_mfma_w(const Geom &g, const PlanLayout &L, const void *plan, const float *xr, float *xs, int64_t n,
-                         int64_t Cr, int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream)
+static int launch_mfma_w(const Geom &g, const PlanLayout &L, const void *plan, const float *xr, float *xs, bool x_in_plan,
+                         int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream)
 {
     const char *base = (const char *)plan;
     const int *to = (const int *)(base + L.off_offsets);
     const float *spos = (const float *)(base + L.off_spos);
-    const int *perm = xr ? (const int *)(base + L.off_perm) : nullptr;
+    const int *perm = xr && !x_in_plan ? (const int *)(base + L.off_perm) : nullptr;
     switch (g.m) {
-    case 1: return launch_mfma_t<4, OWNED>(g, L, plan, to, spos, perm, xr, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 2: return launch_mfma_t<6, OWNED>(g, L, plan, to, spos, perm, xr, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 3: return launch_mfma_t<8, OWNED>(g, L, plan, to, spos, perm, xr, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 4: return launch_mfma_t<10, OWNED>(g, L, plan, to, spos, perm, xr, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 5: return launch_mfma_t<12, OWNED>(g, L, plan, to, spos, perm, xr, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 6: return launch_mfma_t<14, OWNED>(g, L, plan, to, spos, perm, xr, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 7: return launch_mfma_t<16, OWNED>(g, L, plan, to, spos, perm, xr, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 1: return launch_mfma_t<4, OWNED>(g, L, plan, to, spos, perm, xr, xs, x_in_plan, n, Cr, plane0, nplanes, grid, stream);
+    case 2: return launch_mfma_t<6, OWNED>(g, L, plan, to, spos, perm, xr, xs, x_in_plan, n, Cr, plane0, nplanes, grid, stream);
+    case 3: return launch_mfma_t<8, OWNED>(g, L, plan, to, spos, perm, xr, xs, x_in_plan, n, Cr, plane0, nplanes, grid, stream);
+    case 4: return launch_mfma_t<10, OWNED>(g, L, plan, to, spos, perm, xr, xs, x_in_plan, n, Cr, plane0, nplanes, grid, stream);
+    case 5: return launch_mfma_t<12, OWNED>(g, L, plan, to, spos, perm, xr, xs, x_in_plan, n, Cr, plane0, nplanes, grid, stream);
+    case 6: return launch_mfma_t<14, OWNED>(g, L, plan, to, spos, perm, xr, xs, x_in_plan, n, Cr, plane0, nplanes, grid, stream);
+    case 7: return launch_mfma_t<16, OWNED>(g, L, plan, to, spos, perm, xr, xs, x_in_plan, n, Cr, plane0, nplanes, grid, stream);
     }
     set_error("matrix-core spreading supports cutoff 1..7");
     return 1;
@@ -647,16 +681,20 @@ static int launch_mfma_w(const Geom &g, const PlanLayout &L, const void *plan, c
 // entries than that (owned tiling).  The owned variant writes every cell of the planes: no zero-fill needed.
 // xs: the coefficients in plan order, column after column (stride L.cap).  xr == nullptr: the caller has filled it
 // (gather_rows); else the kernel fills it from xr, the row-major [point][Cr] array, through the plan's permutation.
+// x_in_plan: the plan was built with this call's single real coefficient column (launch_plan_points with x): the
+// records carry it, xr / xs are not read.
 int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, const float *xr, float *xs,
-                       int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream)
+                       int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream,
+                       bool x_in_plan)
 {
     if (nplanes <= 0) return 0;
     if (n <= 0) {
         if (g.owned) NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(nplanes * g.cells * 4), stream));
         return 0;
     }
-    return g.owned ? launch_mfma_w<true>(g, L, plan, xr, xs, n, Cr, plane0, nplanes, grid, stream)
-                   : launch_mfma_w<false>(g, L, plan, xr, xs, n, Cr, plane0, nplanes, grid, stream);
+    if (Cr != 1) x_in_plan = false;
+    return g.owned ? launch_mfma_w<true>(g, L, plan, xr, xs, x_in_plan, n, Cr, plane0, nplanes, grid, stream)
+                   : launch_mfma_w<false>(g, L, plan, xr, xs, x_in_plan, n, Cr, plane0, nplanes, grid, stream);
 }
 
 } // namespace nfft

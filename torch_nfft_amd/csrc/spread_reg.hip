@@ -119,9 +119,10 @@ spread_reg_kernel(const Geom g, const int *__restrict__ tile_offsets, const floa
                     float f0 = 0.f, f1 = 0.f, f2 = 0.f, xv = 0.f;
                     bool hit = false;
                     if (j < e) {
-                        split_cell(spos[(int64_t)j * 3 + 0], g.M, c0, f0);
-                        split_cell(spos[(int64_t)j * 3 + 1], g.M, c1, f1);
-                        split_cell(spos[(int64_t)j * 3 + 2], g.M, c2, f2);
+                        const f32x4 rec = *(const f32x4 *)(spos + (int64_t)j * 4);  // plan record {p0, p1, p2, x}
+                        split_cell(rec.x, g.M, c0, f0);
+                        split_cell(rec.y, g.M, c1, f1);
+                        split_cell(rec.z, g.M, c2, f2);
                         xv = xcol[j] * norm;
                         c1 -= o1;  // in [-kSub, 2 kSub): row of the point's cell relative to the owned rows
                         c2 -= o2;

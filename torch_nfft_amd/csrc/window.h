@@ -5,6 +5,8 @@
 
 namespace nfft {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 template <int DIM, int W>
 struct TapCfg {
     static constexpr TileCfg tc = tile_cfg(DIM, W);
@@ -67,9 +69,10 @@ struct PointPrep {
         int c0 = 0, c1 = 0, c2 = 0;
         f0 = f1 = f2 = 0.0f;
         if (DIM == 3) {
-            split_cell(spos[j * 3 + 0], g.M, c0, f0);
-            split_cell(spos[j * 3 + 1], g.M, c1, f1);
-            split_cell(spos[j * 3 + 2], g.M, c2, f2);
+            const f32x4 rec = *(const f32x4 *)(spos + j * 4);  // {p0, p1, p2, x}
+            split_cell(rec.x, g.M, c0, f0);
+            split_cell(rec.y, g.M, c1, f1);
+            split_cell(rec.z, g.M, c2, f2);
         } else if (DIM == 2) {
             split_cell(spos[j * 2 + 0], g.M, c1, f1);
             split_cell(spos[j * 2 + 1], g.M, c2, f2);
