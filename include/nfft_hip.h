@@ -105,17 +105,6 @@ int nfft_hip_adjoint_planned(const nfft_hip_problem *p, const void *plan, const 
 int nfft_hip_forward_planned(const nfft_hip_problem *p, const void *plan, const void *xhat, int x_is_complex,
                              int real_output, void *y, void *workspace, int64_t workspace_bytes, void *stream);
 
-/* Adjoint transform that BUILDS the point plan on the way and leaves it in the caller's buffer `plan`
- * (nfft_hip_plan_bytes) for later *_planned calls on the same points: same result as nfft_hip_plan_points followed by
- * nfft_hip_adjoint_planned, but a single real coefficient column travels with the points through the plan's sort, so
- * the spreading kernel does not have to gather it through the permutation (the reference's counterpart of the plan,
- * shifts + psi, is likewise computed inside its adjoint call: core_cuda.cu:188-211).  This is what the operator
- * layer calls when its plan cache misses.  The coefficients stored in the plan are those of THIS call only; later
- * planned calls read their own x. */
-int nfft_hip_adjoint_build_plan(const nfft_hip_problem *p, const float *pos, const int64_t *batch, void *plan,
-                                int64_t plan_bytes, const void *x, int x_is_complex, int real_output, void *y,
-                                void *workspace, int64_t workspace_bytes, void *stream);
-
 /* ---- stage-level entry points (used by the parity tests and by bench.py to time
  * the spreading kernel on its own; the two calls above are built from them) ---- */
 
@@ -135,7 +124,8 @@ int nfft_hip_plan_points(const nfft_hip_problem *p, const float *pos, const int6
  *   grid  float32 [B*Cr, (2N)^dim] real planes; every cell is written by this call.
  *   scratch  nfft_hip_spread_scratch_bytes(p, Cr) bytes: the tile-ordered copy of xr (n * Cr floats, or one per plan
  *            entry when the problem is sparse enough for the owner-computes kernel, whose plan enters a point into
- *            every tile its window touches). */
+ *            every tile its window touches) and one word per plane (its largest |x|, the operand scale of the
+ *            matrix-core kernel). */
 int64_t nfft_hip_spread_scratch_bytes(const nfft_hip_problem *p, int64_t real_columns);
 int nfft_hip_spread(const nfft_hip_problem *p, const void *plan, const float *xr, int64_t real_columns,
                     float *grid, float *scratch, void *stream);

@@ -70,6 +70,34 @@ __global__ void __launch_bounds__(256) random_dword(const int *__restrict__ idx,
     }
     if (s == 123.456f) out[0] = s;
 }
+// the same with TWO reads per index, 64 bytes apart inside one aligned 128-byte line: if the counter does not grow against
+// random_dword, a random read fetches (and the counter under-reports) a whole 128-byte line; if it doubles, the memory-side
+// request is 64 bytes and the raw counter is exact for this pattern
+__global__ void __launch_bounds__(256) random_pair64(const int *__restrict__ idx, const float *__restrict__ table, size_t n,
+                                                     float *out)
+{
+    float s = 0.f;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 8 * step) {
+        int j[8];
+        for (int q = 0; q < 8; ++q) j[q] = i0 + q * step < n ? (idx[i0 + q * step] & ~31) : -1;  // 128-byte aligned
+        for (int q = 0; q < 8; ++q) s += j[q] >= 0 ? table[j[q]] + table[j[q] + 16] : 0.f;
+    }
+    if (s == 123.456f) out[0] = s;
+}
+// ... and 32 bytes apart inside one aligned 64-byte half line
+__global__ void __launch_bounds__(256) random_pair32(const int *__restrict__ idx, const float *__restrict__ table, size_t n,
+                                                     float *out)
+{
+    float s = 0.f;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 8 * step) {
+        int j[8];
+        for (int q = 0; q < 8; ++q) j[q] = i0 + q * step < n ? (idx[i0 + q * step] & ~31) : -1;
+        for (int q = 0; q < 8; ++q) s += j[q] >= 0 ? table[j[q]] + table[j[q] + 8] : 0.f;
+    }
+    if (s == 123.456f) out[0] = s;
+}
 // the index stream alone (to subtract)
 __global__ void __launch_bounds__(256) index_stream(const int *__restrict__ idx, size_t n, float *out)
 {
@@ -116,6 +144,8 @@ int main()
         hipLaunchKernelGGL(stream_lds_dma, dim3(blocks), dim3(256), 0, 0, a, big / 4, out);
         hipLaunchKernelGGL(index_stream, dim3(blocks), dim3(256), 0, 0, idx, nrand, out);
         hipLaunchKernelGGL(random_dword, dim3(blocks), dim3(256), 0, 0, idx, a, nrand, out);
+        hipLaunchKernelGGL(random_pair64, dim3(blocks), dim3(256), 0, 0, idx, a, nrand, out);
+        hipLaunchKernelGGL(random_pair32, dim3(blocks), dim3(256), 0, 0, idx, a, nrand, out);
         hipLaunchKernelGGL(atomic_rows, dim3(blocks), dim3(256), 0, 0, a, big / 4);
         hipLaunchKernelGGL(random_store, dim3(blocks), dim3(256), 0, 0, idx, a, nrand);
         CHECK(hipDeviceSynchronize());
@@ -125,6 +155,7 @@ int main()
            big * 4 / 1024, (big / 3) * 12 / 1024, big / 4 * 4 / 1024);
     printf("  index_stream    %zu\n  random_dword    %zu index stream + %zu reads x {4 B payload, 32 B, 64 B, 128 B} = %zu / %zu / %zu / %zu\n",
            nrand * 4 / 1024, nrand * 4 / 1024, nrand, nrand * 4 / 1024, nrand * 32 / 1024, nrand * 64 / 1024, nrand * 128 / 1024);
+    printf("  random_pair64 / random_pair32: as random_dword with a second read 64 / 32 bytes away in the same 128-byte line\n");
     printf("  atomic_rows     %zu written\n  random_store    %zu index stream read, %zu stores x {4, 32, 64 B} = %zu / %zu / %zu written\n",
            big / 4 * 4 / 1024, nrand * 4 / 1024, nrand, nrand * 4 / 1024, nrand * 32 / 1024, nrand * 64 / 1024);
     return 0;

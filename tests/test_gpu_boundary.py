@@ -396,59 +396,11 @@ def test_operators_under_inference_mode(tn):
     assert after["hits"] == before["hits"]  # inference points never hit (or enter) the cache
 
 
-# ----------------------------------------------------------------------------- adjoint that builds its plan
-
-def test_adjoint_build_plan_carries_coefficients_through_the_sort(tn):
-    """nfft_hip_adjoint_build_plan (what the operator layer calls on a plan-cache miss): the single real coefficient
-    column rides through the plan's sort into the fourth float of the 16-byte plan records and the spreading kernel
-    runs without its permutation pass.  Checked against the oracle, against the two-call route (plan_points +
-    adjoint_planned, which gathers x through the permutation), and the plan it leaves behind is then used with OTHER
-    coefficients (the stored ones must be ignored) and by the forward transform.  Dense problem (scatter kernel) and
-    sparse one (owner-computes kernel: one record per touched tile), two point sets."""
-    from torch_nfft_amd import _lib
-    lib = _lib.load()
-    rng = np.random.default_rng(91)
-    for N, n in ((64, 140000), (64, 9000)):
-        m, B = 4, 2
-        pos = (rng.random((n, 3)) - 0.5).astype(np.float32)
-        batch = np.sort(rng.integers(0, B, n)).astype(np.int64)
-        batch[0], batch[-1] = 0, B - 1
-        x = rng.standard_normal(n).astype(np.float32)
-        x2 = rng.standard_normal(n).astype(np.float32)
-        post, bt, xt, x2t = dev(pos), dev(batch), dev(x), dev(x2)
-        prob = _lib.Problem(3, n, 1, B, N, m)
-        nb = lib.nfft_hip_adjoint_workspace_bytes(ctypes.byref(prob), 0, 0)
-        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
-        pb = lib.nfft_hip_plan_bytes(ctypes.byref(prob))
-        plan_a = torch.empty(pb, dtype=torch.uint8, device="cuda")
-        plan_b = torch.empty(pb, dtype=torch.uint8, device="cuda")
-        y_fused = torch.empty((B, N, N, N), dtype=torch.complex64, device="cuda")
-        y_two = torch.empty_like(y_fused)
-        y_other = torch.empty_like(y_fused)
-        _lib.check(lib.nfft_hip_adjoint_build_plan(ctypes.byref(prob), _p(post), _p(bt), _p(plan_a), pb, _p(xt), 0, 0,
-                                                   _p(y_fused), _p(ws), nb, _stream()))
-        _lib.check(lib.nfft_hip_plan_points(ctypes.byref(prob), _p(post), _p(bt), _p(plan_b), pb, _stream()))
-        _lib.check(lib.nfft_hip_adjoint_planned(ctypes.byref(prob), _p(plan_b), _p(xt), 0, 0, _p(y_two), _p(ws), nb, _stream()))
-        ref = nfft_ref.nfft_adjoint(x, pos, batch, N=N, m=m)
-        assert rel_l2(host(y_fused), ref) < 2e-6 and rel_l2(host(y_two), ref) < 2e-6
-        # the plan left behind, with other coefficients: what it stores for x must not leak into the result
-        _lib.check(lib.nfft_hip_adjoint_planned(ctypes.byref(prob), _p(plan_a), _p(x2t), 0, 0, _p(y_other), _p(ws), nb, _stream()))
-        assert rel_l2(host(y_other), nfft_ref.nfft_adjoint(x2, pos, batch, N=N, m=m)) < 2e-6
-        # ... and by the forward transform
-        nbf = lib.nfft_hip_forward_workspace_bytes(ctypes.byref(prob), 1, 1)
-        wsf = torch.empty(nbf, dtype=torch.uint8, device="cuda")
-        f_a = torch.empty(n, device="cuda")
-        f_b = torch.empty(n, device="cuda")
-        _lib.check(lib.nfft_hip_forward_planned(ctypes.byref(prob), _p(plan_a), _p(y_two), 1, 1, _p(f_a), _p(wsf), nbf, _stream()))
-        _lib.check(lib.nfft_hip_forward_planned(ctypes.byref(prob), _p(plan_b), _p(y_two), 1, 1, _p(f_b), _p(wsf), nbf, _stream()))
-        assert torch.equal(f_a, f_b)
-        _lib.check_status()
-
+# ----------------------------------------------------------------------------- plan reuse
 
 def test_operator_cache_miss_and_hit_routes_agree(tn):
-    """torch.ops.torch_nfft.nfft_adjoint on a plan-cache miss builds the plan inside the adjoint call (coefficients carried
-    by the sort); on a hit it takes the planned entry point (coefficients gathered through the permutation).  Same
-    numbers either way, for real (carried) and complex (never carried) coefficients."""
+    """torch.ops.torch_nfft.nfft_adjoint on a plan-cache miss and on a hit (the same plan, other coefficient arrays read
+    through the index in the plan records): same numbers, real and complex coefficients, against the oracle."""
     from torch_nfft_amd import ops
     rng = np.random.default_rng(92)
     n, N, m = 200000, 64, 4
@@ -466,3 +418,31 @@ def test_operator_cache_miss_and_hit_routes_agree(tn):
         assert s1["misses"] == s0["misses"] + 1 and s1["hits"] == s0["hits"] + 1
         assert rel_l2(host(y_hit), host(y_miss)) < 1e-6
         assert rel_l2(host(y_miss), nfft_ref.nfft_adjoint(x, host(pos), None, N=N, m=m)) < 2e-6
+
+
+def test_unsorted_batch_vector_is_reported(tn):
+    """The operand scales of the matrix-core spreading kernel are the largest |x| of every point set, taken over the set's
+    ROW RANGE (the batch vector is sorted, docs/source/theory/dataformat.rst:35-37).  A point whose set index is out of
+    order can carry a coefficient far above the maximum that was found for its set: the kernel clamps it (no operand
+    leaves the f16 range) and reports it -- the call fails with "Input mismatch" instead of returning a wrong spectrum."""
+    from torch_nfft_amd import ops
+    rng = np.random.default_rng(17)
+    n, N, m = 6000, 32, 3
+    pos = dev((rng.random((n, 3)) - 0.5).astype(np.float32))
+    batch = np.repeat(np.arange(2), n // 2).astype(np.int64)
+    x = np.ones(n, dtype=np.float32)
+    batch[100], x[100] = 1, 1000.0  # belongs to set 1 but sits in the rows of set 0
+    ops.plan_cache_clear()
+    ops.check_status()
+    with pytest.raises(RuntimeError, match="Input mismatch: the batch vector is not sorted"):
+        tn.nfft_adjoint(dev(x), pos, dev(batch), bandwidth=N, cutoff=m)
+        ops.check_status()
+    try:
+        ops.check_status()
+    except RuntimeError:
+        pass
+    ops.plan_cache_clear()
+    batch[100] = 0
+    y = tn.nfft_adjoint(dev(x), pos, dev(batch), bandwidth=N, cutoff=m)
+    ops.check_status()
+    assert rel_l2(host(y), nfft_ref.nfft_adjoint(x, host(pos), batch, N=N, m=m)) < 2e-6

@@ -358,7 +358,7 @@ def test_spread_stage_matches_oracle(tn):
     _lib.check(lib.nfft_hip_plan_points(ctypes.byref(prob), p(post), p(batcht), p(plan), plan.numel(), s))
     M = 2 * N
     grid = torch.full((B * Cr,) + (M,) * d, float("nan"), device="cuda")
-    scratch = torch.empty(n * Cr + 128, device="cuda")
+    scratch = torch.empty(lib.nfft_hip_spread_scratch_bytes(ctypes.byref(prob), Cr) // 4, device="cuda")
     _lib.check(lib.nfft_hip_spread(ctypes.byref(prob), p(plan), p(xt), Cr, p(grid), p(scratch), s))
     ref = nfft_ref.spread(x, pos, batch, N, m).real.reshape((B * Cr,) + (M,) * d)
     assert rel_l2(host(grid), ref) < T1

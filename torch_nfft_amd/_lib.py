@@ -26,7 +26,6 @@ SYMBOLS = (
     "nfft_hip_forward",
     "nfft_hip_adjoint_planned",
     "nfft_hip_forward_planned",
-    "nfft_hip_adjoint_build_plan",
     "nfft_hip_plan_bytes",
     "nfft_hip_plan_points",
     "nfft_hip_spread_scratch_bytes",
@@ -100,8 +99,6 @@ def load():
     for f in (lib.nfft_hip_adjoint_planned, lib.nfft_hip_forward_planned):
         f.argtypes = [P, vp, vp, ci, ci, vp, vp, i64, vp]
         f.restype = ci
-    lib.nfft_hip_adjoint_build_plan.argtypes = [P, vp, vp, vp, i64, vp, ci, ci, vp, vp, i64, vp]
-    lib.nfft_hip_adjoint_build_plan.restype = ci
     lib.nfft_hip_plan_bytes.argtypes = [P]
     lib.nfft_hip_plan_bytes.restype = i64
     lib.nfft_hip_plan_points.argtypes = [P, vp, vp, vp, i64, vp]

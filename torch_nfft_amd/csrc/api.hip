@@ -114,6 +114,7 @@ const char *const kFaultText[kNumFaults] = {
     "the result of that forward transform is invalid",
     "Input mismatch: batch holds an index outside [0, batch_size) (the batch vector must be sorted with "
     "batch[-1] + 1 == batch_size)",
+    "Input mismatch: the batch vector is not sorted (a coefficient exceeds the largest one of its point set's row range)",
 };
 }  // namespace
 
@@ -142,7 +143,7 @@ static int take_pending_fault()
         if (blk[k]) {
             blk[k] = 0;
             set_error(kFaultText[k]);
-            return k == kFaultBatchIndex ? NFFT_HIP_EINVAL : NFFT_HIP_EKERNEL;
+            return k == kFaultStreamStall ? NFFT_HIP_EKERNEL : NFFT_HIP_EINVAL;
         }
     }
     return 0;
@@ -232,17 +233,12 @@ PlanSet plan_set(const nfft_hip_problem *p)
     }
     return ps;
 }
-// x (optional): the single real coefficient column of the adjoint call the plan is built in; it rides through the sort
-// into the records of the plan the spreading kernel walks (carries_x), which then needs no permutation pass
-int build_plans(const PlanSet &ps, const float *pos, const int64_t *batch, int64_t n, int64_t B, void *plan, hipStream_t s,
-                const float *x = nullptr)
+int build_plans(const PlanSet &ps, const float *pos, const int64_t *batch, int64_t n, int64_t B, void *plan, hipStream_t s)
 {
-    if (int rc = launch_plan_points(ps.g, ps.L, pos, batch, n, B, plan, s, ps.owned ? nullptr : x)) return rc;
-    if (ps.owned) return launch_plan_points(ps.go, ps.Lo, pos, batch, n, B, (char *)plan + ps.off_own, s, x);
+    if (int rc = launch_plan_points(ps.g, ps.L, pos, batch, n, B, plan, s)) return rc;
+    if (ps.owned) return launch_plan_points(ps.go, ps.Lo, pos, batch, n, B, (char *)plan + ps.off_own, s);
     return 0;
 }
-// the plan records have room for a coefficient (3-D) and the sort can carry it (two-level path)
-bool carries_x(const PlanSet &ps) { return ps.spread_geom().dim == 3 && ps.spread_layout().two_level; }
 
 // interpolation: matrix-core kernels for the wide 3-D tiling (the wave-per-column one from 4 real columns up) unless
 // NFFT_HIP_GATHER=lds (lane-per-point kernel) or =mfma (always the plane-ring kernel)
@@ -302,15 +298,16 @@ struct Carve {
     int64_t n, B, C, Cr, total_planes, chunk_planes;
     int64_t half_cells;
     bool colfft;  // pruned column passes (colfft.hip) instead of the full dim-dimensional rocFFT transform
-    int64_t off_plan, off_xs, off_grid, off_spec, off_col, off_work, work_bytes, total;
+    int64_t off_plan, off_xs, off_xmax, off_grid, off_spec, off_col, off_work, work_bytes, total;
 };
 
 bool spread_reg_enabled() { return subblock_plan_enabled(); }
 
-// The matrix-core spreading kernel permutes one or two real coefficient columns itself (its pass over a work item's
-// points that finds their largest |x| reads the caller's row-major array through the plan's permutation and leaves
-// the plan-ordered copy in xs): no separate permutation pass, 0.18 ms at C3.  With more columns one pass
-// (gather_rows) reads every row once for all of them.  NFFT_HIP_XGATHER=1 always runs the separate pass.
+// The matrix-core spreading kernel reads one or two real coefficient columns in place: every plan record carries the
+// index of its point in the caller's arrays and the staging pipeline fetches x[index] two steps ahead of its use -- no
+// permutation pass (0.18 ms at C3 as a kernel of its own, a 23 us latency-bound prologue per work item inside the
+// spreading kernel).  With more columns one pass (gather_rows) reads every row once for all of them.
+// NFFT_HIP_XGATHER=1 always runs the separate pass.
 bool spread_permutes(const Geom &g, int64_t Cr)
 {
     static const bool off = [] {
@@ -320,15 +317,16 @@ bool spread_permutes(const Geom &g, int64_t Cr)
     return !off && spread_mfma_supported(g) && Cr <= 2;
 }
 
-// xs: the planar copy in plan order; xr: nullptr when the caller has filled xs, else what spread_permutes() reads
-int spread_any(const Geom &g, const PlanLayout &L, const void *plan, const float *xr, float *xs, int64_t n, int64_t Cr,
-               int64_t p0, int64_t np, float *grid, hipStream_t s, bool x_in_plan = false)
+// xs: the planar copy in plan order; xr: nullptr when the caller has filled xs, else what spread_permutes() reads;
+// xmax: per-plane largest |x| (matrix-core kernel only: launch_plane_absmax)
+int spread_any(const Geom &g, const PlanLayout &L, const void *plan, const float *xr, float *xs, const unsigned *xmax,
+               int64_t n, int64_t Cr, int64_t p0, int64_t np, float *grid, hipStream_t s)
 {
     if (spread_mfma_supported(g)) {
         // (the owner-computes variant writes every cell itself)
         if (!g.owned) { StageTimer t(kStageZero, s); NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(np * g.cells * 4), s)); }
         StageTimer t(kStageSpread, s);
-        return launch_spread_mfma(g, L, plan, xr, xs, n, Cr, p0, np, grid, s, x_in_plan);
+        return launch_spread_mfma(g, L, plan, xr, xs, xmax, n, Cr, p0, np, grid, s);
     }
     if (spread_reg_supported(g) && spread_reg_enabled()) {
         StageTimer t(kStageSpread, s);
@@ -393,6 +391,7 @@ int make_carve(const nfft_hip_problem *p, int planes_per_col, bool need_xs, FftK
     int64_t o = 0;
     c.off_plan = o; o = align_up(o + c.ps.total, 256);
     c.off_xs = o;   o = align_up(o + (need_xs ? (align_up(c.ps.spread_layout().cap * c.Cr, 64) + 64) * 4 : 0), 256);
+    c.off_xmax = o; o = align_up(o + (need_xs ? c.total_planes * 4 : 0), 256);
     c.off_grid = o; o = align_up(o + chunk * c.g.cells * 4, 256);
     c.off_spec = o; o = align_up(o + chunk * c.half_cells * 8, 256);
     c.off_col = o;  o = align_up(o + (c.colfft ? colfft_scratch_bytes(c.g, chunk) : 0), 256);
@@ -477,7 +476,8 @@ int nfft_hip_plan_points(const nfft_hip_problem *p, const float *pos, const int6
 int64_t nfft_hip_spread_scratch_bytes(const nfft_hip_problem *p, int64_t real_columns)
 {
     if (validate(p) || real_columns < 0) return -1;
-    return (align_up(plan_set(p).spread_layout().cap * real_columns, 64) + 64) * 4;
+    // plan-ordered copy of the coefficients + one word per plane (its largest |x|)
+    return (align_up(plan_set(p).spread_layout().cap * real_columns, 64) + 64 + align_up(p->batch_size * real_columns, 64)) * 4;
 }
 
 int nfft_hip_spread(const nfft_hip_problem *p, const void *plan, const float *xr, int64_t real_columns, float *grid,
@@ -488,13 +488,17 @@ int nfft_hip_spread(const nfft_hip_problem *p, const void *plan, const float *xr
     const PlanSet ps = plan_set(p);
     const Geom &g = ps.spread_geom();
     const PlanLayout &L = ps.spread_layout();
+    const void *const halo_plan = plan;
     plan = ps.spread_plan(plan);
     hipStream_t s = (hipStream_t)stream;
     const int64_t planes = p->batch_size * real_columns;
     if (planes > 32768) { set_error("Input mismatch: too many planes for one spread call"); return NFFT_HIP_EINVAL; }
-    if (spread_permutes(g, real_columns)) return spread_any(g, L, plan, xr, scratch, p->num_points, real_columns, 0, planes, grid, s);
+    unsigned *xmax = (unsigned *)(scratch + align_up(L.cap * real_columns, 64) + 64);
+    if (spread_mfma_supported(g))
+        if (int rc = launch_plane_absmax(ps.g, ps.L, halo_plan, xr, p->num_points, p->batch_size, real_columns, xmax, s)) return rc;
+    if (spread_permutes(g, real_columns)) return spread_any(g, L, plan, xr, scratch, xmax, p->num_points, real_columns, 0, planes, grid, s);
     if (int rc = launch_gather_rows(g, L, plan, p->num_points, xr, real_columns, scratch, s)) return rc;
-    return spread_any(g, L, plan, nullptr, scratch, p->num_points, real_columns, 0, planes, grid, s);
+    return spread_any(g, L, plan, nullptr, scratch, xmax, p->num_points, real_columns, 0, planes, grid, s);
 }
 
 int nfft_hip_interpolate(const nfft_hip_problem *p, const void *plan, const float *grid, int64_t real_columns,
@@ -509,12 +513,9 @@ int nfft_hip_interpolate(const nfft_hip_problem *p, const void *plan, const floa
     return gather_any(g, L, plan, grid, p->num_points, real_columns, 0, planes, yr, (hipStream_t)stream);
 }
 
-// ext_plan: an existing plan (pos / batch unused), or nullptr: the plan is built here -- into plan_out if the caller
-// wants to keep it (nfft_hip_adjoint_build_plan), else into the workspace
 static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64_t *batch, const void *ext_plan,
                         const void *x, int x_is_complex, int real_output, void *y, void *workspace,
-                        int64_t workspace_bytes, void *stream, const void *mult = nullptr, int mult_kind = 0,
-                        void *plan_out = nullptr)
+                        int64_t workspace_bytes, void *stream, const void *mult = nullptr, int mult_kind = 0)
 {
     if (int rc = take_pending_fault()) return rc;  // a kernel of an earlier call gave up: say so
     if (int rc = validate(p)) return rc;
@@ -533,23 +534,25 @@ static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64
     float2 *spec = (float2 *)(ws + c.off_spec);
     void *work = ws + c.off_work;
 
-    const Geom &gs = c.ps.spread_geom();
-    const PlanLayout &Ls = c.ps.spread_layout();
-    const bool fused = spread_permutes(gs, c.Cr);
-    // a plan built in this call takes the (single, real) coefficient column along through its sort: no permutation
-    // pass anywhere (the spreading kernel's own one costs it ~7 % at config C3: a latency-bound prologue per work item)
-    const bool x_in_plan = !ext_plan && fused && c.Cr == 1 && carries_x(c.ps);
     if (!ext_plan) {
         StageTimer t(kStagePlan, s);
-        void *dst = plan_out ? plan_out : (void *)(ws + c.off_plan);
-        if (int rc = build_plans(c.ps, pos, batch, c.n, c.B, dst, s, x_in_plan ? (const float *)x : nullptr)) return rc;
-        plan = dst;
+        if (int rc = build_plans(c.ps, pos, batch, c.n, c.B, ws + c.off_plan, s)) return rc;
+        plan = ws + c.off_plan;
     }
+    const Geom &gs = c.ps.spread_geom();
+    const PlanLayout &Ls = c.ps.spread_layout();
     const void *plan_s = c.ps.spread_plan(plan);
+    const bool fused = spread_permutes(gs, c.Cr);
+    unsigned *xmax = (unsigned *)(ws + c.off_xmax);
+    if (spread_mfma_supported(gs)) {
+        // operand scales of the matrix-core kernel: one streaming pass over x for all planes of the call
+        StageTimer t(kStageGather, s);
+        if (int rc = launch_plane_absmax(c.g, c.L, plan, (const float *)x, c.n, c.B, c.Cr, xmax, s)) return rc;
+    }
     if (!fused) { StageTimer t(kStageGather, s); if (int rc = launch_gather_rows(gs, Ls, plan_s, c.n, (const float *)x, c.Cr, xs, s)) return rc; }
     for (int64_t p0 = 0; p0 < c.total_planes; p0 += c.chunk_planes) {
         const int64_t np = std::min(c.chunk_planes, c.total_planes - p0);
-        if (int rc = spread_any(gs, Ls, plan_s, fused ? (const float *)x : nullptr, xs, c.n, c.Cr, p0, np, grid, s, x_in_plan)) return rc;
+        if (int rc = spread_any(gs, Ls, plan_s, fused ? (const float *)x : nullptr, xs, xmax, c.n, c.Cr, p0, np, grid, s)) return rc;
         if (c.colfft) {
             const bool own_rows = own_row_passes(c.g);
             if (own_rows) { StageTimer t(kStageFft, s); if (int rc = launch_row_r2c(c.g, grid, ws + c.off_col, c.chunk_planes, np, spec, s)) return rc; }
@@ -629,17 +632,6 @@ int nfft_hip_adjoint(const nfft_hip_problem *p, const float *pos, const void *x,
                      void *stream)
 {
     return adjoint_impl(p, pos, batch, nullptr, x, x_is_complex, real_output, y, workspace, workspace_bytes, stream);
-}
-
-int nfft_hip_adjoint_build_plan(const nfft_hip_problem *p, const float *pos, const int64_t *batch, void *plan,
-                                int64_t plan_bytes, const void *x, int x_is_complex, int real_output, void *y,
-                                void *workspace, int64_t workspace_bytes, void *stream)
-{
-    if (int rc = validate(p)) return rc;
-    if (!plan || plan_bytes < plan_set(p).total) { set_error("plan buffer too small"); return NFFT_HIP_EWORKSPACE; }
-    if (p->num_points > 0 && !pos) { set_error("Input mismatch: pos is null"); return NFFT_HIP_EINVAL; }
-    return adjoint_impl(p, pos, batch, nullptr, x, x_is_complex, real_output, y, workspace, workspace_bytes, stream,
-                        nullptr, 0, plan);
 }
 
 int nfft_hip_forward(const nfft_hip_problem *p, const float *pos, const void *xhat, int x_is_complex,

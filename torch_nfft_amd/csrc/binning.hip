@@ -34,7 +34,7 @@ PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)
     int64_t o = 0;
     L.off_offsets = o; o = align_up(o + (L.ntiles + 1) * 4, 256);
     L.off_cursor = o;  o = align_up(o + (L.ntiles + 1) * 4, 256);
-    L.off_perm = o;    o = align_up(o + L.cap * 4, 256);
+    L.off_perm = o;    o = align_up(o + (g.dim == 3 ? 0 : L.cap * 4), 256);  // (3-D: the index sits in the record)
     L.off_spos = o;    o = align_up(o + L.cap * g.pstride * 4, 256);
     L.off_scan = o;    o = align_up(o + L.scan_bytes, 256);
     // scratch of the two-level sort: per-(pencil, block) counts + their scan, and the pencil-ordered records
@@ -51,7 +51,6 @@ PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)
     // two or three more split_cell + tile-index evaluations)
     L.off_key1 = o;    o = align_up(o + (L.two_level && !g.owned ? n * 2 : 0), 256);
     L.off_key2 = o;    o = align_up(o + (L.two_level ? L.cap * 2 : 0), 256);
-    L.off_tmpx = o;    o = align_up(o + (L.two_level && g.dim == 3 ? L.cap * 4 : 0), 256);
     L.total = o;
     return L;
 }
@@ -92,17 +91,16 @@ __global__ void __launch_bounds__(256) bin_count_kernel(Geom g, const float *__r
 __global__ void __launch_bounds__(256) bin_fill_kernel(Geom g, const float *__restrict__ pos,
                                                       const int64_t *__restrict__ batch, int64_t n, int64_t B,
                                                       const int *__restrict__ offsets, int *__restrict__ cursor,
-                                                      int *__restrict__ perm, float *__restrict__ spos,
-                                                      const float *__restrict__ x)
+                                                      int *__restrict__ perm, float *__restrict__ spos)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int tiles[4];
         const int k = point_tiles(g, pos, batch, i, B, tiles);
         for (int q = 0; q < k; ++q) {
             const int slot = offsets[tiles[q]] + atomicAdd(&cursor[tiles[q]], 1);
-            perm[slot] = (int)i;
             for (int u = 0; u < g.dim; ++u) spos[(int64_t)slot * g.pstride + u] = pos[i * g.dim + u];
-            if (g.dim == 3) spos[(int64_t)slot * 4 + 3] = x ? x[i] : 0.0f;
+            if (g.dim == 3) spos[(int64_t)slot * 4 + 3] = __int_as_float((int)i);
+            else perm[slot] = (int)i;
         }
     }
 }
@@ -212,8 +210,7 @@ sort1_count_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restr
 __global__ void __launch_bounds__(kSortThreads)
 sort1_scatter_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restrict__ batch, int64_t n, int64_t B,
                      int npencils, int nblocks, const int *__restrict__ hscan, const unsigned short *__restrict__ key1,
-                     float4 *__restrict__ tmp, const float *__restrict__ x /* optional: one coefficient per point ... */,
-                     float *__restrict__ tmpx /* ... which travels next to the point's record */)
+                     float4 *__restrict__ tmp)
 {
     extern __shared__ int lds_cur[];
     for (int i = threadIdx.x; i < npencils; i += kSortThreads) lds_cur[i] = hscan[(int64_t)i * nblocks + blockIdx.x];
@@ -221,7 +218,7 @@ sort1_scatter_kernel(Geom g, const float *__restrict__ pos, const int64_t *__res
     const int64_t lo = (int64_t)blockIdx.x * kSortBlockPoints;
     const int64_t hi = min(n, lo + kSortBlockPoints);
     for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)kSortThreads * kSortUnroll) {
-        float c0[kSortUnroll], c1[kSortUnroll], c2[kSortUnroll], xx[kSortUnroll];
+        float c0[kSortUnroll], c1[kSortUnroll], c2[kSortUnroll];
         int64_t bb[kSortUnroll];
         int kk[kSortUnroll];
 #pragma unroll
@@ -231,7 +228,6 @@ sort1_scatter_kernel(Geom g, const float *__restrict__ pos, const int64_t *__res
             load_point(pos, g.dim, i, live, c0[q], c1[q], c2[q]);
             bb[q] = live && batch && g.owned ? batch[i] : 0;
             kk[q] = live && !g.owned ? key1[i] : 0;
-            xx[q] = live && x ? x[i] : 0.0f;
         }
 #pragma unroll
         for (int q = 0; q < kSortUnroll; ++q) {
@@ -248,7 +244,6 @@ sort1_scatter_kernel(Geom g, const float *__restrict__ pos, const int64_t *__res
             for (int r = 0; r < k; ++r) {
                 const int slot = atomicAdd(&lds_cur[bins[r]], 1);
                 tmp[slot] = make_float4(c0[q], c1[q], c2[q], __int_as_float((int)i));
-                if (x) tmpx[slot] = xx[q];
             }
         }
     }
@@ -328,8 +323,7 @@ sort2_count_kernel(Geom g, int nblocks, const int *__restrict__ hscan, const flo
 __global__ void __launch_bounds__(kSortThreads)
 sort2_scatter_kernel(Geom g, int npencils, int nblocks, const int *__restrict__ hscan, const float4 *__restrict__ tmp,
                      const int *__restrict__ hist2, const unsigned short *__restrict__ key2, int *__restrict__ offsets,
-                     int *__restrict__ groups, int *__restrict__ perm, float *__restrict__ spos,
-                     const float *__restrict__ tmpx /* nullptr: the plan carries no coefficients (fourth float = 0) */)
+                     int *__restrict__ groups, int *__restrict__ perm, float *__restrict__ spos)
 {
     extern __shared__ int lds2[];  // [fine keys] this part's cursors, [fine keys] totals over the parts
     const int l1 = blockIdx.x, part = blockIdx.y;
@@ -384,24 +378,23 @@ sort2_scatter_kernel(Geom g, int npencils, int nblocks, const int *__restrict__ 
     for (int j0 = r0 + threadIdx.x; j0 < r1; j0 += kSortThreads * 8) {
         float4 recs[8];
         int keys[8];
-        float xv[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int j = j0 + q * kSortThreads;
             recs[q] = j < r1 ? tmp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
             keys[q] = j < r1 ? key2[j] : 0;  // (left by the count pass)
-            xv[q] = j < r1 && tmpx ? tmpx[j] : 0.0f;
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             if (j0 + q * kSortThreads >= r1) continue;
             const float4 rec = recs[q];
             const int slot = atomicAdd(&lds2[keys[q]], 1);
-            perm[slot] = __float_as_int(rec.w);
             if (g.dim == 3) {
-                // one aligned 16-byte store {p0, p1, p2, x} (the pass is bound by scattered store requests, not bytes)
-                ((float4 *)spos)[slot] = make_float4(rec.x, rec.y, rec.z, xv[q]);
+                // the 16-byte record {p0, p1, p2, index of the point} moves as it is: ONE scattered store per point (the
+                // pass is bound by scattered store requests, not bytes; there is no separate permutation array in 3-D)
+                ((float4 *)spos)[slot] = rec;
             } else {
+                perm[slot] = __float_as_int(rec.w);
                 spos[(int64_t)slot * g.dim] = rec.x;
                 if (g.dim > 1) spos[(int64_t)slot * g.dim + 1] = rec.y;
             }
@@ -503,7 +496,8 @@ item_order_kernel(Geom g, int pencils, int runs, const int *__restrict__ offsets
 
 // xs[c, slot] = xr[perm[slot], c]  (tile-ordered, column-major copy of the real coefficient columns; column stride
 // `stride` = plan capacity, `*total` = entries the plan holds)
-__global__ void __launch_bounds__(256) gather_rows_kernel(const int *__restrict__ perm, const float *__restrict__ xr,
+__global__ void __launch_bounds__(256) gather_rows_kernel(const int *__restrict__ perm /* stride pstep ints */, const int pstep,
+                                                         const float *__restrict__ xr,
                                                          float *__restrict__ xs, const int *__restrict__ total_entries,
                                                          int64_t stride, int64_t cols)
 {
@@ -520,7 +514,7 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const int *__restrict_
             const int64_t e = e0 + q * step;
             if (e < total) {
                 const int64_t slot = e / cols, c = e - slot * cols;
-                src[q] = (int64_t)perm[slot] * cols + c;
+                src[q] = (int64_t)perm[slot * pstep] * cols + c;
             } else {
                 src[q] = -1;
             }
@@ -563,9 +557,8 @@ static void launch_segment_split(const Geom &g, int64_t n, int64_t B, const int 
 }
 
 int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, const int64_t *batch, int64_t n, int64_t B,
-                       void *plan, hipStream_t stream, const float *x)
+                       void *plan, hipStream_t stream)
 {
-    if (g.dim != 3) x = nullptr;  // (only the 16-byte records of 3-D plans have room for a coefficient)
     char *base = (char *)plan;
     int *offsets = (int *)(base + L.off_offsets);
     int *cursor = (int *)(base + L.off_cursor);
@@ -586,14 +579,13 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
         if ((int64_t)scan_bytes > L.scan_bytes) { set_error("scan scratch too small"); return 2; }
         NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(base + L.off_scan, scan_bytes, hist, hscan, (int)items, stream));
         hipLaunchKernelGGL(sort1_scatter_kernel, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
-                           npencils, nblocks, hscan, key1, tmp, x, (float *)(base + L.off_tmpx));
+                           npencils, nblocks, hscan, key1, tmp);
         int *hist2 = (int *)(base + L.off_hist2);
         const size_t lds2 = (size_t)g.l1bins * g.SB * g.CG * 4;
         hipLaunchKernelGGL(sort2_count_kernel, dim3(npencils, kSort2Parts), dim3(kSortThreads), lds2, stream, g, nblocks,
                            hscan, tmp, hist2, key2);
         hipLaunchKernelGGL(sort2_scatter_kernel, dim3(npencils, kSort2Parts), dim3(kSortThreads), 2 * lds2, stream, g,
-                           npencils, nblocks, hscan, tmp, hist2, key2, offsets, (int *)(base + L.off_groups), perm, spos,
-                           x ? (const float *)(base + L.off_tmpx) : nullptr);
+                           npencils, nblocks, hscan, tmp, hist2, key2, offsets, (int *)(base + L.off_groups), perm, spos);
         if (g.wide) {
             // the record area is free now: it holds the overflow list of the load-balance split
             NFFT_HIP_CHECK(hipMemsetAsync(tmp, 0, 16, stream));
@@ -617,7 +609,7 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
     NFFT_HIP_CHECK(hipMemsetAsync(cursor, 0, (L.ntiles + 1) * 4, stream));
     if (n > 0) {
         hipLaunchKernelGGL(bin_fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, g, pos, batch, n, B, offsets,
-                           cursor, perm, spos, x);
+                           cursor, perm, spos);
     }
     // (no record area in this path: ranges stay whole; the cursors are no longer needed)
     if (g.wide) launch_segment_split(g, n, B, offsets, cursor, nullptr, 0, (int *)(base + L.off_order), stream);
@@ -628,11 +620,12 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
 int launch_gather_rows(const Geom &g, const PlanLayout &L, const void *plan, int64_t n, const float *xr, int64_t cols,
                        float *xs, hipStream_t stream)
 {
-    const int *perm = (const int *)((const char *)plan + L.off_perm);
+    // 3-D: the original index of a point is the fourth word of its 16-byte plan record
+    const int *perm = g.dim == 3 ? (const int *)((const char *)plan + L.off_spos) + 3 : (const int *)((const char *)plan + L.off_perm);
     const int *total = (const int *)((const char *)plan + L.off_offsets) + L.ntiles;  // offsets[ntiles] = entries
     if (n * cols > 0)
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(L.cap * cols, 256)), dim3(256), 0, stream, perm, xr, xs,
-                           total, L.cap, cols);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(L.cap * cols, 256)), dim3(256), 0, stream, perm,
+                           g.dim == 3 ? 4 : 1, xr, xs, total, L.cap, cols);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -26,7 +26,7 @@ void set_error(const std::string &msg);
 // fault is pending).  The reference aborts the process on a device error (csrc/cuda/cuda_utils.cu:5-16); here the
 // next call returns NFFT_HIP_EKERNEL.  One int per fault kind: plain system-scope stores, no read-modify-write
 // across the bus.
-enum DeviceFault { kFaultStreamStall = 0, kFaultBatchIndex = 1, kNumFaults = 2 };
+enum DeviceFault { kFaultStreamStall = 0, kFaultBatchIndex = 1, kFaultBatchOrder = 2, kNumFaults = 3 };
 constexpr int kStatusInts = 16;  // ints per device block (a 64-byte line)
 int *device_status_block();      // api.hip: device-visible address of the current device's block (nullptr: none)
 
@@ -103,9 +103,9 @@ struct Geom {
     // or gather block of one group needs two of the tile's four 16-column k-steps / one of its two 32-column halves:
     // the matrix-core kernels skip the rest.  tile_offsets keeps one entry per slab.
     int CG;
-    // floats per point of the plan's tile-ordered copy: 3-D points are 16-byte records {p0, p1, p2, x} -- the fourth float
-    // carries the point's (single, real) coefficient when the plan is built inside an adjoint call (binning.hip), else 0 --
-    // so that every consumer loads a point with one aligned 16-byte access; 1-D / 2-D keep dim floats
+    // floats per point of the plan's tile-ordered copy: 3-D points are 16-byte records {p0, p1, p2, index of the point
+    // in the caller's arrays (int bits)} -- one aligned 16-byte access per point for every consumer, one scattered store
+    // per point for the sort, no separate permutation array; 1-D / 2-D keep dim floats + the permutation array
     int pstride;
     int64_t cells; // M^dim
 };
@@ -349,7 +349,6 @@ struct PlanLayout {
     int64_t off_groups;  // column-group starts (two ints per plan bin) when `grouped`
     int64_t off_order;   // wide tiling: work items of every point set in launch order, biggest first (binning.hip)
     int64_t off_key1, off_key2;  // sort scratch: first-level bin of every point, fine key of every record (16 bits each)
-    int64_t off_tmpx;            // sort scratch: the coefficient that travels with a first-level record (plans built with x)
     bool grouped;        // the plan is ordered by column group inside the slabs (Geom::CG == 3, two-level sort)
     int64_t total;
 };

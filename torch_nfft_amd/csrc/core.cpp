@@ -281,28 +281,9 @@ at::Tensor nfft_adjoint(at::Tensor pos, at::Tensor x, c10::optional<at::Tensor> 
     const int64_t ws_bytes = nfft_hip_adjoint_workspace_bytes(&q, real_input ? 0 : 1, real_output ? 1 : 0);
     if (ws_bytes < 0) check_rc(std::string(nfft_hip_last_error()).rfind("Input mismatch", 0) == 0 ? NFFT_HIP_EINVAL : NFFT_HIP_EFFT);
     at::Tensor ws = byte_buffer(ws_bytes, x);
-    {
-        // cached plan: the planned entry; miss: the adjoint builds the plan itself (the coefficients ride through the
-        // plan's sort, nfft_hip_adjoint_build_plan) and the plan goes into the cache for the calls that follow
-        std::unique_lock<std::mutex> lock(g_cache.mutex);
-        const PlanLookup lk = plan_lookup_key(p, q);
-        at::Tensor plan = cache_find(lk);
-        if (!plan.defined() && lk.stream == stream_of(x)) {
-            ++g_cache.misses;
-            int64_t nbytes = 0;
-            plan = new_plan_buffer(p, q, nbytes);
-            check_rc(nfft_hip_adjoint_build_plan(&q, p.pos.data_ptr<float>(),
-                                                 p.batch.defined() ? p.batch.data_ptr<int64_t>() : nullptr, plan.data_ptr(),
-                                                 nbytes, xc.data_ptr(), real_input ? 0 : 1, real_output ? 1 : 0, y.data_ptr(),
-                                                 ws.data_ptr(), ws_bytes, lk.stream));
-            cache_insert(lk, p, plan);
-            return y;
-        }
-        lock.unlock();
-        if (!plan.defined()) plan = get_plan(p, q);
-        check_rc(nfft_hip_adjoint_planned(&q, plan.data_ptr(), xc.data_ptr(), real_input ? 0 : 1, real_output ? 1 : 0,
-                                          y.data_ptr(), ws.data_ptr(), ws_bytes, stream_of(x)));
-    }
+    const at::Tensor plan = get_plan(p, q);
+    check_rc(nfft_hip_adjoint_planned(&q, plan.data_ptr(), xc.data_ptr(), real_input ? 0 : 1, real_output ? 1 : 0,
+                                      y.data_ptr(), ws.data_ptr(), ws_bytes, stream_of(x)));
     return y;
 }
 

@@ -200,7 +200,7 @@ interp_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__r
                 }
                 acc0 = fmaf(p0, plane_acc.x + plane_acc.y, acc0);
             }
-            yr[(int64_t)perm[j] * Cr + cr] = acc0 * norm;
+            yr[(int64_t)(DIM == 3 ? __float_as_int(spos[(int64_t)j * 4 + 3]) : perm[j]) * Cr + cr] = acc0 * norm;  // (3-D: the index sits in the record)
         }
     }
 }

@@ -301,7 +301,7 @@ interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
             const int c = cr0 + w;
             const int64_t pl = (int64_t)b * Cr + c;
             if (c < Cr && pl >= plane0 && pl < plane0 + nplanes)
-                yr[(int64_t)perm[c_begin + p] * Cr + c] = ystage[p * kIcStageStride + w];
+                yr[(int64_t)__float_as_int(spos[(int64_t)(c_begin + p) * 4 + 3]) * Cr + c] = ystage[p * kIcStageStride + w];
         }
     }
     }  // work items

@@ -252,7 +252,7 @@ interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
                 y = fmaf(p0, t, y);
             }
             y += __shfl_xor(y, 32);  // the two row halves of the point
-            if (valid && h == 0) yr[(int64_t)perm[j] * Cr + cr] = y * norm;
+            if (valid && h == 0) yr[(int64_t)__float_as_int(spos[(int64_t)j * 4 + 3]) * Cr + cr] = y * norm;  // (index: fourth word of the record)
         }
     }
     }  // work items

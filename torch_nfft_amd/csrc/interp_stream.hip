@@ -321,7 +321,7 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
             if (idx >= 0) {
                 const f32x4 v = *(const f32x4 *)(spos + (int64_t)idx * 4);  // plan record {p0, p1, p2, x}: one aligned load
                 a0 = v.x; a1 = v.y; a2 = v.z;
-                pm = perm[idx];
+                pm = __float_as_int(v.w);  // index of the point in the caller's arrays
             }
         };
         int blk = claim();

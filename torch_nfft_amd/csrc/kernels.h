@@ -5,10 +5,8 @@
 namespace nfft {
 
 // binning.hip
-// x (optional, 3-D plans): one real coefficient per point that travels with the point through the sort and ends up as
-// the fourth float of its plan record -- the spreading kernel then needs no permutation pass (launch_spread_mfma)
 int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, const int64_t *batch, int64_t n, int64_t B,
-                       void *plan, hipStream_t stream, const float *x = nullptr);
+                       void *plan, hipStream_t stream);
 // xs[c * n + slot] = xr[perm[slot] * cols + c]
 int launch_gather_rows(const Geom &g, const PlanLayout &L, const void *plan, int64_t n, const float *xr, int64_t cols,
                        float *xs, hipStream_t stream);
@@ -25,11 +23,15 @@ int launch_spread_reg(const Geom &g, const PlanLayout &L, const void *plan, cons
 
 // spread_mfma.hip: matrix-core spreading for the wide 3-D tiling (g.wide)
 bool spread_mfma_supported(const Geom &g);
-// (xs = coefficients in plan order, planar; with xr != nullptr the kernel fills it from the caller's row-major array)
-// x_in_plan: the plan's records carry the (single, real) coefficient column of this call: no permutation pass at all
-int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, const float *xr, float *xs,
-                       int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream,
-                       bool x_in_plan = false);
+// largest |x| per (point set, real column) plane -> xmax[B * Cr] (bit patterns): the kernel's operand scales.  Reads the
+// caller's row-major [point][Cr] array; set boundaries come from the halo plan (the batch vector is sorted)
+int launch_plane_absmax(const Geom &g_halo, const PlanLayout &L_halo, const void *plan_halo, const float *xr, int64_t n,
+                        int64_t B, int64_t Cr, unsigned *xmax, hipStream_t stream);
+// coefficients: xr (row-major [point][Cr], read through the index in the plan records) or, when xr == nullptr, xs (copy in
+// plan order, planar, stride L.cap: gather_rows)
+int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, const float *xr, const float *xs,
+                       const unsigned *xmax, int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, float *grid,
+                       hipStream_t stream);
 
 // interp.hip: yr[perm[slot] * Cr + cr] = sum over taps of grid[p, ...]
 int launch_interp(const Geom &g, const PlanLayout &L, const void *plan, const float *grid, int64_t n, int64_t Cr,

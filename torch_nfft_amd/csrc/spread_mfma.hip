@@ -85,27 +85,35 @@ struct __align__(16) MfmaStage {
     int slab[kNKB];
 };
 
+// Staging rings: the 16-byte plan records of a batch are requested six steps ahead of its MFMAs, its coefficients four
+// steps ahead (their address comes out of the landed record when the kernel gathers x through the plan), the batch is
+// converted two steps ahead.
+constexpr int kRecRing = 8;
+constexpr int kXRing = 4;
 template <int W>
 struct __align__(16) MfmaLds {
     MfmaOps<W> ops[2];
     MfmaStage stag[2];
-    f32x4 raw[2][kSlots];                 // landing zones of the LDS-DMA (batch b uses b & 1): plan records {p0, p1, p2, x}
-    float rawx[2][kSlots];                // ... and the coefficient out of the plan-ordered column (plans built without x)
-    int raw_have[2][kSlots];
-    int raw_slab[2][kNKB];
+    f32x4 raw[kRecRing][kSlots];          // landing zones of the LDS-DMA (batch b uses b & 7): plan records {p0, p1, p2, index}
+    float rawx[kXRing][kSlots];           // ... and of the coefficients (batch b uses b & 3)
+    int raw_idx[kRecRing][kSlots];        // plan entry of the slot (only used with the plan-ordered coefficient copy)
+    signed char raw_have[kRecRing][kSlots];
+    int raw_slab[kRecRing][kNKB];
     int task_counter[2];
-    unsigned xmax_bits;                   // max |x| over the work item's points (bit pattern; staging of the f16 scale)
+    float inv_xscale;                     // (read by the staging threads once per step: a register would be spilled to scratch)
     int2 sched[kMaxSweep + 8];            // per slab: {K-blocks before it, point offset}; padded with the totals
     int sched_end[kMaxSweep + 8];         // per slab: end of its point range
 };
+static_assert(sizeof(MfmaLds<16>) <= 160 * 1024, "LDS budget");
 
 template <int W, bool OVERFLOW, bool OWNED>
 __global__ void __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *__restrict__ spos,
-                   const int *__restrict__ perm, const float *__restrict__ xr, float *__restrict__ xs,
-                   const int64_t xs_stride, const int Cr, const int x_in_plan,
+                   const float *__restrict__ xr, const float *__restrict__ xs, const int64_t xs_stride,
+                   const unsigned *__restrict__ xmax, const int Cr,
                    const int plane0, float *__restrict__ grid, const int seg_slabs, const int nsegm,
-                   const int *__restrict__ first_end, const int *__restrict__ order, const int4 *__restrict__ overflow)
+                   const int *__restrict__ first_end, const int *__restrict__ order, const int4 *__restrict__ overflow,
+                   int *__restrict__ status)
 {
     constexpr int m = W / 2 - 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -160,68 +168,31 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     const float sc = win_exp_scale(m);
     float norm = win_norm(m);
     norm = norm * norm * norm;
-    // coefficients in plan order, one column after the other.  With `perm` the kernel makes that copy itself: the pass
-    // below that finds the item's largest |x| reads the caller's row-major [point][Cr] array through the plan's
-    // permutation and leaves the values in xs (no separate permutation pass over all points: 0.18 ms at C3)
-    float *const xcol = xs + (int64_t)cr * xs_stride;
-    // max |x| over the plan entries [j_begin, j_end), strided over `nthr` threads.  Through the permutation the loads
-    // go out eight at a time: a loop of dependent (index, value) pairs is two HBM latencies per point and thread
-    auto absmax_range = [&](const int j_begin, const int j_end, const int t, const int nthr, float mx) {
-        if (x_in_plan) {
-            // the plan was built with this call's coefficients: they sit in the fourth float of the records
-            for (int j = j_begin + t; j < j_end; j += nthr) mx = fmaxf(mx, fabsf(spos[(int64_t)j * 4 + 3]));
-        } else if (perm) {
-            for (int j0 = j_begin + t; j0 < j_end; j0 += 8 * nthr) {
-                int pj[8];
-                float v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) pj[q] = j0 + q * nthr < j_end ? perm[j0 + q * nthr] : -1;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = pj[q] >= 0 ? xr[(int64_t)pj[q] * Cr + cr] : 0.0f;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    if (pj[q] >= 0) xcol[j0 + q * nthr] = v[q];
-                    mx = fmaxf(mx, fabsf(v[q]));
-                }
-            }
-        } else {
-            for (int j = j_begin + t; j < j_end; j += nthr) mx = fmaxf(mx, fabsf(xcol[j]));
-        }
-        return mx;
-    };
-    // x is scaled into [-1, 1] by a power of two so that every operand fits f16; undone at the flush.  The scale is
-    // this work item's own: the largest |x| among the points of its slab range in its column -- columns, point sets or
-    // regions of very different magnitude each keep their full ~22 bits (a single global scale would flush a column
-    // 1e-10 below the largest one to zero; the reference spreads every column independently in fp32).
-    if (tid == 0) L.xmax_bits = 0u;
-    __syncthreads();
-    {
-        float mx = 0.0f;
-        if (OWNED) {
-            for (int k = wave; k < nslab; k += kMfmaThreads / 64) {
-                const int sw = wrap(s_lo + k, g.M);
-                mx = absmax_range(tile_offsets[bin0 + sw], tile_offsets[bin0 + sw + 1], lane, 64, mx);
-            }
-        } else {
-            mx = absmax_range(tile_offsets[bin0 + sb], tile_offsets[bin0 + se], tid, kMfmaThreads, mx);
-        }
-        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-        // non-negative floats order like their bit patterns (inf saturates the scale, which is clamped below)
-        if (lane == 0 && mx > 0.0f) atomicMax(&L.xmax_bits, __float_as_uint(mx));
-    }
-    __syncthreads();
+    // Coefficients: either the caller's row-major [point][Cr] array `xr`, read through the index that every plan record
+    // carries (one or two real columns: no permutation pass anywhere), or `xs`, a copy in plan order, one column after
+    // the other (gather_rows: more columns).  Both arrive through the staging pipeline below.
+    const float *const xcol = xs + (int64_t)cr * xs_stride;
+    // x is scaled into [-1, 1] by a power of two so that every operand fits f16; undone at the flush.  The scale is the
+    // plane's own -- the largest |x| of its point set in its column, found by plane_absmax_kernel before the launch --
+    // so columns and point sets of very different magnitude each keep their full ~22 bits (a single scale for the whole
+    // call would flush a column 1e-10 below the largest one to zero; the reference spreads every column independently
+    // in fp32).  (Until round 3 every work item scanned its own points for it: a latency-bound prologue, 7 % of the
+    // kernel's time at config C3, profiles/r03_spread_trace.txt.)
     float xscale = 1.0f;
     {
-        const float mx = __uint_as_float(L.xmax_bits);
+        const float mx = __uint_as_float(xmax[plane]);
         if (mx > 1.0e-30f && mx < 3.0e38f) {  // (tinier inputs: 1 / scale would overflow; their taps flush to zero anyway)
             int e;
             frexpf(mx, &e);
             xscale = ldexpf(1.0f, e);
         }
     }
+    // (wave-uniform: keep the scales in scalar registers -- the kernel sits at its 128-VGPR limit)
+    xscale = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(xscale)));
     NFFT_TRACE(1, __builtin_amdgcn_s_memrealtime());
-    const float inv_xscale = 1.0f / xscale;
-    const float unscale = xscale * norm * (1.0f / (kOpScale * kOpScale));
+    if (tid == 0) L.inv_xscale = 1.0f / xscale;  // (visible behind the barriers of the schedule set-up below)
+    const float unscale =
+        __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(xscale * norm * (1.0f / (kOpScale * kOpScale)))));
     float *const gplane = grid + (int64_t)plane_local * g.cells;
 
     f32x16 acc0 = 0.0f, acc1 = 0.0f;
@@ -345,10 +316,12 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
         continue;
     }
 
-    // ---- staging of a batch: thread -> (K-block, point).  The points of batch i + 4 are requested (LDS-DMA into
-    // L.raw[i & 1]) while batch i is accumulated and converted to (cell, fraction) form two steps later: under the
-    // atomic traffic of the flushes a load takes longer than one step.  Every request issues exactly two DMA
-    // instructions per wave (lanes without a point read a dummy address), so that the consumer can wait with a count.
+    // ---- staging of a batch: thread -> (K-block, point).  While batch i is accumulated the records of batch i + 6 are
+    // requested (LDS-DMA into L.raw[(i + 6) & 7]), the coefficients of batch i + 4 (their records have landed and say
+    // where the point's coefficient lives), and batch i + 2 is converted to (cell, fraction, scaled value) form: every
+    // load has two steps to arrive -- under the atomic traffic of the flushes one step is not enough.  Every step issues
+    // exactly two DMA instructions per wave (lanes without a point read a dummy address), so that the consumer can
+    // wait with a count.
     int cur = 0;  // slab of this thread's previous K-block (K-blocks only move forward)
     // this thread's slot of a batch: plan index of its point (any valid one for a padding slot), whether it has one,
     // the K-block's slab (unwrapped)
@@ -378,23 +351,33 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
             if (!have) idx = e0.y;  // any valid point: the value is not used
         }
     };
-    auto issue_dma = [&](const int batch, const int idx, const int have, const int slab, const float *xsrc) {
-        const int j = st / kKB, i = st - j * kKB;
-        const int buf = batch & 1;
-        lds_dma_dwordx4(spos + (int64_t)idx * 4, &L.raw[buf][(wave - kStageWave0) * 64]);
-        lds_dma_dword(xsrc, &L.rawx[buf][(wave - kStageWave0) * 64]);  // (not used when the plan carries x)
-        L.raw_have[buf][st] = have;
-        if (i == 0) L.raw_slab[buf][j] = slab;
-    };
-    auto stage_request = [&](const int batch) {
+    // record request of a batch (B): locate this thread's slot, one 16-byte DMA, bookkeeping for the later steps
+    auto request_records = [&](const int batch) {
         int idx, have, slab;
         locate(batch, idx, have, slab);
-        issue_dma(batch, idx, have, slab, xcol + idx);
+        const int j = st / kKB, i = st - j * kKB;
+        const int buf = batch & (kRecRing - 1);
+        lds_dma_dwordx4(spos + (int64_t)idx * 4, &L.raw[buf][(wave - kStageWave0) * 64]);
+        L.raw_have[buf][st] = (signed char)have;
+        if (i == 0) L.raw_slab[buf][j] = slab;
+        if (!xr) L.raw_idx[buf][st] = idx;
+    };
+    // coefficient request of a batch (A), two steps behind its record request: the record has landed and holds the
+    // index of the point in the caller's arrays
+    auto request_coefficients = [&](const int batch) {
+        const float *src;
+        if (xr) {
+            const int orig = __float_as_int(L.raw[batch & (kRecRing - 1)][st].w);  // (padding slots hold a valid record)
+            src = xr + (int64_t)orig * Cr + cr;
+        } else {
+            src = xcol + L.raw_idx[batch & (kRecRing - 1)][st];
+        }
+        lds_dma_dword(src, &L.rawx[batch & (kXRing - 1)][(wave - kStageWave0) * 64]);
     };
     auto stage_convert = [&](MfmaStage &S, const int batch, const bool newest_in_flight) {
-        const int buf = batch & 1;
-        // the stager waves of the 12-owner layout issue no other vector-memory traffic: a counted wait leaves the
-        // request behind this one in flight (plane-owner waves also have flush atomics outstanding: wait for all)
+        const int buf = batch & (kRecRing - 1);
+        // the stager waves of the 12-owner layout issue no other vector-memory traffic: a counted wait leaves the two
+        // requests of the previous step in flight (plane-owner waves also have flush atomics outstanding: wait for all)
         if (newest_in_flight && NOWN != 16) wait_lds_dma_but_newest(); else wait_lds_dma();
         float f0 = 0.f, f1 = 0.f, f2 = 0.f, xv = 0.f;
         int c1 = -1000, c2 = -1000;  // padding slots: outside every window
@@ -415,7 +398,13 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                 c1 -= tb1 - m;  // row of the point's cell inside the padded pencil (tap l1 sits at row c1 - m + l1)
                 c2 -= tb2 - m;
             }
-            xv = (x_in_plan ? rec.w : L.rawx[buf][st]) * inv_xscale;
+            xv = L.rawx[batch & (kXRing - 1)][st] * L.inv_xscale;
+            // |x| above the plane's maximum: the batch vector is not sorted (the maxima are taken over the row range
+            // of every point set).  Reported; the value is clamped so that no operand leaves the f16 range.
+            if (!(fabsf(xv) <= 1.0f)) {
+                if (xv == xv) report_fault(status, kFaultBatchOrder);  // (a NaN coefficient is the caller's business)
+                xv = fminf(fmaxf(xv, -1.0f), 1.0f);
+            }
         }
         S.f0[st] = f0; S.f1[st] = f1; S.f2[st] = f2; S.x[st] = xv;
         S.c1[st] = c1; S.c2[st] = c2;
@@ -575,10 +564,12 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     // Requests past the last batch are dummies that keep the count of outstanding DMA instructions uniform.
     if (tid < 2) L.task_counter[tid] = 0;
     if (stager) {
-        stage_request(0);
+        // fill the pipeline: records of batches 0 .. 4, then (they have landed) the coefficients of 0 .. 2, then batch 0
+        for (int q = 0; q < 5; ++q) request_records(q);
+        wait_lds_dma();
+        for (int q = 0; q < 3; ++q) request_coefficients(q);
+        wait_lds_dma();
         stage_convert(L.stag[0], 0, false);
-        stage_request(1);
-        stage_request(2);
     }
     __syncthreads();
     NFFT_TRACE(2, __builtin_amdgcn_s_memrealtime());
@@ -586,7 +577,8 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     for (int i = -1; i < nbatch; ++i) {
         if (stager) {
             if (i + 2 < nbatch) stage_convert(L.stag[i & 1], i + 2, true);
-            stage_request(i + 4);
+            request_coefficients(i + 4);
+            request_records(i + 6);
         }
         if (tid == 0) L.task_counter[i & 1] = 0;  // for the next step; its last user is behind the previous barrier
         if (i >= 0 && owner) accumulate(L.ops[i & 1], min(kNKB, total - i * kNKB));
@@ -618,9 +610,65 @@ extern "C" int nfft_dbg_set_spread_trace(void *device_buffer)
 }
 #endif
 
+// Largest |x| of every (point set, real column) plane: the power-of-two operand scale of the spreading kernel.
+// `xr` is the caller's row-major [point][Cr] array; the batch vector is sorted, so point set b is the row range
+// [rows[b], rows[b + 1]) with rows[b] = plan entries in front of set b in the (halo) plan.  Non-negative floats order
+// like their bit patterns, so the maxima are taken with integer atomics.
+__global__ void __launch_bounds__(256)
+plane_absmax_kernel(const int *__restrict__ tile_offsets, const int64_t bins_per_set, const float *__restrict__ xr,
+                    const int Cr, unsigned *__restrict__ xmax)
+{
+    __shared__ unsigned lmax[256];
+    const int b = blockIdx.y;
+    const int64_t e0 = (int64_t)tile_offsets[b * bins_per_set] * Cr, e1 = (int64_t)tile_offsets[(b + 1) * bins_per_set] * Cr;
+    const int64_t chunk = (e1 - e0 + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = e0 + chunk * blockIdx.x, hi = min(e1, lo + chunk);
+    const bool fixed_col = 256 % Cr == 0;  // then a thread sees one column only: e = lo' + t + 256 k
+    if (!fixed_col && Cr > 256) {
+        for (int64_t e = lo + threadIdx.x; e < hi; e += 256) {
+            const unsigned v = __float_as_uint(fabsf(xr[e]));
+            if (v) atomicMax(&xmax[(int64_t)b * Cr + (int)(e % Cr)], v);
+        }
+        return;
+    }
+    lmax[threadIdx.x] = 0u;
+    __syncthreads();
+    if (fixed_col) {
+        const int64_t lo_al = lo - lo % Cr;  // start on a row boundary so that column = thread % Cr
+        float mx = 0.0f;
+        for (int64_t e = lo_al + threadIdx.x; e < hi; e += 256)
+            if (e >= lo) mx = fmaxf(mx, fabsf(xr[e]));
+        if (Cr == 1) {
+            for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+            if ((threadIdx.x & 63) == 0) atomicMax(&lmax[0], __float_as_uint(mx));
+        } else {
+            atomicMax(&lmax[threadIdx.x % Cr], __float_as_uint(mx));
+        }
+    } else {
+        for (int64_t e = lo + threadIdx.x; e < hi; e += 256) atomicMax(&lmax[(int)(e % Cr)], __float_as_uint(fabsf(xr[e])));
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < Cr && lmax[threadIdx.x]) atomicMax(&xmax[(int64_t)b * Cr + threadIdx.x], lmax[threadIdx.x]);
+}
+
+int launch_plane_absmax(const Geom &g_halo, const PlanLayout &L_halo, const void *plan_halo, const float *xr, int64_t n,
+                        int64_t B, int64_t Cr, unsigned *xmax, hipStream_t stream)
+{
+    if (B * Cr <= 0) return 0;
+    NFFT_HIP_CHECK(hipMemsetAsync(xmax, 0, (size_t)(B * Cr * 4), stream));
+    if (n <= 0) return 0;
+    const int *to = (const int *)((const char *)plan_halo + L_halo.off_offsets);
+    int64_t blocks = (n * Cr / B + 256 * 16 - 1) / (256 * 16);  // ~16 elements per thread
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(plane_absmax_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, stream, to,
+                       (int64_t)g_halo.tiles_per_batch * g_halo.SB, xr, (int)Cr, xmax);
+    NFFT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 template <int W, bool OWNED>
 static int launch_mfma_t(const Geom &g, const PlanLayout &L, const void *plan, const int *to, const float *spos,
-                         const int *perm, const float *xr, float *xs, bool x_in_plan, int64_t n, int64_t Cr, int64_t plane0,
+                         const float *xr, const float *xs, const unsigned *xmax, int64_t n, int64_t Cr, int64_t plane0,
                          int64_t nplanes, float *grid, hipStream_t stream)
 {
     // Ranges per pencil: about 5-6 workgroups per CU balance the tail of the launch against the 2m+1 halo planes
@@ -643,35 +691,38 @@ static int launch_mfma_t(const Geom &g, const PlanLayout &L, const void *plan, c
     const char *base = (const char *)plan;
     const int *first_end = (const int *)(base + L.off_cursor);
     const int *order = (const int *)(base + L.off_order);
+    int *const status = device_status_block();
     hipLaunchKernelGGL((spread_mfma_kernel<W, false, OWNED>), blocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to,
-                       spos, perm, xr, xs, L.cap, (int)Cr, x_in_plan ? 1 : 0, (int)plane0, grid, seg_slabs, nsegm, first_end, order, (const int4 *)nullptr);
+                       spos, xr, xs, L.cap, xmax, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, order,
+                       (const int4 *)nullptr, status);
     if (L.two_level) {
         // the pieces the plan cut off dense ranges (none for uniform inputs: the workgroups then leave at once)
         const int4 *overflow = (const int4 *)(base + L.off_tmp);
         const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
         hipLaunchKernelGGL((spread_mfma_kernel<W, true, OWNED>), oblocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g,
-                           to, spos, perm, xr, xs, L.cap, (int)Cr, x_in_plan ? 1 : 0, (int)plane0, grid, seg_slabs, nsegm, first_end, order, overflow);
+                           to, spos, xr, xs, L.cap, xmax, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, order,
+                           overflow, status);
     }
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 template <bool OWNED>
-static int launch_mfma_w(const Geom &g, const PlanLayout &L, const void *plan, const float *xr, float *xs, bool x_in_plan,
-                         int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream)
+static int launch_mfma_w(const Geom &g, const PlanLayout &L, const void *plan, const float *xr, const float *xs,
+                         const unsigned *xmax, int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, float *grid,
+                         hipStream_t stream)
 {
     const char *base = (const char *)plan;
     const int *to = (const int *)(base + L.off_offsets);
     const float *spos = (const float *)(base + L.off_spos);
-    const int *perm = xr && !x_in_plan ? (const int *)(base + L.off_perm) : nullptr;
     switch (g.m) {
-    case 1: return launch_mfma_t<4, OWNED>(g, L, plan, to, spos, perm, xr, xs, x_in_plan, n, Cr, plane0, nplanes, grid, stream);
-    case 2: return launch_mfma_t<6, OWNED>(g, L, plan, to, spos, perm, xr, xs, x_in_plan, n, Cr, plane0, nplanes, grid, stream);
-    case 3: return launch_mfma_t<8, OWNED>(g, L, plan, to, spos, perm, xr, xs, x_in_plan, n, Cr, plane0, nplanes, grid, stream);
-    case 4: return launch_mfma_t<10, OWNED>(g, L, plan, to, spos, perm, xr, xs, x_in_plan, n, Cr, plane0, nplanes, grid, stream);
-    case 5: return launch_mfma_t<12, OWNED>(g, L, plan, to, spos, perm, xr, xs, x_in_plan, n, Cr, plane0, nplanes, grid, stream);
-    case 6: return launch_mfma_t<14, OWNED>(g, L, plan, to, spos, perm, xr, xs, x_in_plan, n, Cr, plane0, nplanes, grid, stream);
-    case 7: return launch_mfma_t<16, OWNED>(g, L, plan, to, spos, perm, xr, xs, x_in_plan, n, Cr, plane0, nplanes, grid, stream);
+    case 1: return launch_mfma_t<4, OWNED>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
+    case 2: return launch_mfma_t<6, OWNED>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
+    case 3: return launch_mfma_t<8, OWNED>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
+    case 4: return launch_mfma_t<10, OWNED>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
+    case 5: return launch_mfma_t<12, OWNED>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
+    case 6: return launch_mfma_t<14, OWNED>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
+    case 7: return launch_mfma_t<16, OWNED>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
     }
     set_error("matrix-core spreading supports cutoff 1..7");
     return 1;
@@ -679,22 +730,20 @@ static int launch_mfma_w(const Geom &g, const PlanLayout &L, const void *plan, c
 
 // `n` is the problem's point count (it fixes the work decomposition the plan was built for); the plan may hold more
 // entries than that (owned tiling).  The owned variant writes every cell of the planes: no zero-fill needed.
-// xs: the coefficients in plan order, column after column (stride L.cap).  xr == nullptr: the caller has filled it
-// (gather_rows); else the kernel fills it from xr, the row-major [point][Cr] array, through the plan's permutation.
-// x_in_plan: the plan was built with this call's single real coefficient column (launch_plan_points with x): the
-// records carry it, xr / xs are not read.
-int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, const float *xr, float *xs,
-                       int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream,
-                       bool x_in_plan)
+// Coefficients: xr != nullptr: the caller's row-major [point][Cr] array, read through the index in the plan records
+// (one or two real columns); else xs, the copy in plan order, column after column with stride L.cap (gather_rows).
+// xmax: largest |x| of every plane [B * Cr] (launch_plane_absmax), indexed by the global plane number plane0 + p.
+int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, const float *xr, const float *xs,
+                       const unsigned *xmax, int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, float *grid,
+                       hipStream_t stream)
 {
     if (nplanes <= 0) return 0;
     if (n <= 0) {
         if (g.owned) NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(nplanes * g.cells * 4), stream));
         return 0;
     }
-    if (Cr != 1) x_in_plan = false;
-    return g.owned ? launch_mfma_w<true>(g, L, plan, xr, xs, x_in_plan, n, Cr, plane0, nplanes, grid, stream)
-                   : launch_mfma_w<false>(g, L, plan, xr, xs, x_in_plan, n, Cr, plane0, nplanes, grid, stream);
+    return g.owned ? launch_mfma_w<true>(g, L, plan, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream)
+                   : launch_mfma_w<false>(g, L, plan, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
 }
 
 } // namespace nfft
