@@ -442,15 +442,21 @@ segment_split_kernel(Geom g, int npl /* point sets x pencils */, int runs, int t
 
 // Launch order of the work items of one point set, biggest first: the kernels take item order[blockIdx.x] instead of
 // item blockIdx.x.  Workgroups are dispatched in index order, one per CU (LDS-bound), ~5.4 per CU: with the pencils in
-// grid order the last workgroups to start are as big as any and the launch ends with a quarter of the CUs idle
-// (measured at config C3: 90 % CU utilisation; edge pencils hold 6/23 or 17/55 of a full pencil's points).  Longest
-// first, the tail is made of the small items.  Counting sort into 1024 size classes; one workgroup per point set.
+// grid order the last workgroups to start are as big as any and a clustered input leaves most CUs idle behind its few
+// heavy ranges (measured at C3-clustered: 43 % CU utilisation over the primary launch).  Longest first, the tail is made
+// of the small items.  A STABLE counting sort into 16 size classes (sixteenths of the largest item): items of one
+// class keep their grid order.  Balanced inputs (largest item < 1.5 x the mean item: every uniform input) keep the grid
+// order altogether: neighbouring ranges then run side by side, which measured 1 % faster at config C3 than any sorted
+// order, while the clustered C3 gains 17 % from the sorted one (profiles/r03_experiments.md).  One workgroup per point set.
+constexpr int kOrderClasses = 16;
 __global__ void __launch_bounds__(1024)
 item_order_kernel(Geom g, int pencils, int runs, const int *__restrict__ offsets, const int *__restrict__ first_end,
                   int *__restrict__ order /* [set][pencils * runs] */)
 {
-    __shared__ int cls[1024 + 1];
+    __shared__ int cnt[kOrderClasses][1024];  // [class][thread]: items of the class in the thread's chunk -> their first slot
+    __shared__ int total[kOrderClasses];
     __shared__ int maxpts;
+    __shared__ unsigned long long sumpts;
     const int b = blockIdx.x;
     const int nitems = pencils * runs;
     const int seg_slabs = (g.M + runs - 1) / runs;
@@ -462,35 +468,72 @@ item_order_kernel(Geom g, int pencils, int runs, const int *__restrict__ offsets
         const int *off = offsets + pl * g.np0;
         return off[first_end[pl * kSegMax + seg]] - off[sb];
     };
-    for (int i = threadIdx.x; i <= 1024; i += 1024) cls[i] = 0;
-    if (threadIdx.x == 0) maxpts = 1;
+    if (threadIdx.x == 0) { maxpts = 1; sumpts = 0ull; }
     __syncthreads();
+    // thread t owns the contiguous chunk [t per, (t + 1) per) of the items
+    const int per = (nitems + 1023) / 1024;
+    const int lo = min(nitems, (int)threadIdx.x * per), hi = min(nitems, lo + per);
     int mx = 0;
-    for (int it = threadIdx.x; it < nitems; it += 1024) mx = max(mx, points(it));
+    unsigned long long sm = 0ull;
+    for (int it = lo; it < hi; ++it) {
+        const int pts = points(it);
+        mx = max(mx, pts);
+        sm += (unsigned long long)pts;
+    }
     atomicMax(&maxpts, mx);
+    if (sm) atomicAdd(&sumpts, sm);
     __syncthreads();
-    const float scale = 1023.0f / (float)maxpts;
-    auto size_class = [&](const int pts) { return 1023 - min(1023, (int)((float)pts * scale)); };  // 0 = biggest
-    for (int it = threadIdx.x; it < nitems; it += 1024) atomicAdd(&cls[size_class(points(it)) + 1], 1);
+    if ((double)maxpts * (double)nitems < 1.5 * (double)sumpts) {  // balanced: grid order
+        for (int it = lo; it < hi; ++it) order[(int64_t)b * nitems + it] = it;
+        return;
+    }
+    const float scale = (float)kOrderClasses / (float)maxpts;
+    auto size_class = [&](const int pts) { return kOrderClasses - 1 - min(kOrderClasses - 1, (int)((float)pts * scale)); };  // 0 = biggest
+    int mine[kOrderClasses];
+#pragma unroll
+    for (int c = 0; c < kOrderClasses; ++c) mine[c] = 0;
+    for (int it = lo; it < hi; ++it) {
+        const int c = size_class(points(it));
+#pragma unroll
+        for (int q = 0; q < kOrderClasses; ++q) mine[q] += q == c ? 1 : 0;
+    }
+#pragma unroll
+    for (int c = 0; c < kOrderClasses; ++c) cnt[c][threadIdx.x] = mine[c];
     __syncthreads();
-    if (threadIdx.x < 64) {  // inclusive scan of the 1024 class counts -> first slot of every class
+    // wave c scans class c over the 1024 threads (exclusive); total[c] = the class total
+    {
+        const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
         int carry = 0;
-        for (int base = 1; base <= 1024; base += 64) {
-            const int v = cls[base + threadIdx.x];
+        for (int base = 0; base < 1024; base += 64) {
+            const int v = cnt[c][base + lane];
             int incl = v;
             for (int off = 1; off < 64; off <<= 1) {
                 const int t = __shfl_up(incl, off);
-                if ((int)threadIdx.x >= off) incl += t;
+                if (lane >= off) incl += t;
             }
-            cls[base + threadIdx.x] = carry + incl;
+            cnt[c][base + lane] = carry + incl - v;
             carry += __shfl(incl, 63);
         }
+        if (lane == 0) total[c] = carry;
     }
     __syncthreads();
-    // cls[c] = items in classes before c (cls[0] = 0): cursors
-    for (int it = threadIdx.x; it < nitems; it += 1024) {
-        const int slot = atomicAdd(&cls[size_class(points(it))], 1);
-        order[(int64_t)b * nitems + slot] = it;
+    int slot[kOrderClasses];
+    {
+        int before = 0;
+#pragma unroll
+        for (int c = 0; c < kOrderClasses; ++c) {
+            slot[c] = before + cnt[c][threadIdx.x];
+            before += total[c];
+        }
+    }
+    for (int it = lo; it < hi; ++it) {
+        const int c = size_class(points(it));
+        int s_ = 0;
+#pragma unroll
+        for (int q = 0; q < kOrderClasses; ++q) {
+            if (q == c) { s_ = slot[q]; slot[q] += 1; }
+        }
+        order[(int64_t)b * nitems + s_] = it;
     }
 }
 
