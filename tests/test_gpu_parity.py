@@ -817,3 +817,47 @@ def test_large_1d_grid(tn, log_n):
     assert rel_l2(host(y), ref) < T1
     f = tn.nfft_forward(y, dev(pos), None, cutoff=m)
     assert rel_l2(host(f), nfft_ref.nfft_forward(host(y), pos, None, m=m)) < T1
+
+
+# ----------------------------------------------------------------------------- several columns: column-innermost passes
+
+@pytest.mark.parametrize("N,B,C,complex_x,real_output", [(64, 1, 40, False, False), (64, 2, 24, False, True),
+                                                          (64, 1, 17, True, False), (64, 3, 11, True, True),
+                                                          (128, 1, 33, False, True)])
+def test_many_columns_column_innermost_passes(tn, N, B, C, complex_x, real_output):
+    """Chunks of >= 32 planes with several coefficient columns take the column-innermost FFT passes (groups of 16 planes,
+    plane index innermost; the last adjoint pass writes / the first forward pass reads the reference's [B, N^3, C] layout
+    in place: docs/source/theory/dataformat.rst:43-63, spectral_window_operations.cu:51-111).  Partial last groups, groups
+    that straddle point sets, (re, im) plane pairs, real output: every column against the single-column transform of the
+    same data (the plane-by-plane pipeline), two columns against the oracle."""
+    rng = np.random.default_rng(7 * N + C)
+    m, n = 3, 6000
+    pos = (rng.random((n, 3)) - 0.5).astype(np.float32)
+    batch = None
+    if B > 1:
+        batch = np.sort(rng.integers(0, B, n)).astype(np.int64)
+        batch[0], batch[-1] = 0, B - 1
+    x = rng.standard_normal((n, C)).astype(np.float32)
+    if complex_x:
+        x = (x + 1j * rng.standard_normal((n, C))).astype(np.complex64)
+    pt, bt, xt = dev(pos), dev(batch), dev(x)
+    y = tn.nfft_adjoint(xt, pt, bt, bandwidth=N, cutoff=m, real_output=real_output)
+    assert y.shape == (B, N, N, N, C)
+    for c in rng.choice(C, size=5, replace=False):
+        yc = tn.nfft_adjoint(xt[:, c].contiguous(), pt, bt, bandwidth=N, cutoff=m, real_output=real_output)
+        assert rel_l2(host(y[..., c]), host(yc)) < 1e-6, c
+    for c in (0, C - 1):
+        ref = nfft_ref.nfft_adjoint(x[:, c], pos, batch, N=N, m=m, real_output=real_output)
+        assert rel_l2(host(y[..., c]), ref) < T1W
+    # forward of a random spectrum
+    xh = torch.randn((B, N, N, N, C), device="cuda")
+    if complex_x:
+        xh = torch.complex(xh, torch.randn((B, N, N, N, C), device="cuda"))
+    f = tn.nfft_forward(xh, pt, bt, cutoff=m, real_output=real_output)
+    assert f.shape == (n, C)
+    for c in rng.choice(C, size=5, replace=False):
+        fc = tn.nfft_forward(xh[..., c].contiguous(), pt, bt, cutoff=m, real_output=real_output)
+        assert rel_l2(host(f[:, c]), host(fc)) < 1e-6, c
+    c = C // 2
+    reff = nfft_ref.nfft_forward(host(xh[..., c]), pos, batch, m=m, real_output=real_output)
+    assert rel_l2(host(f[:, c]), reff) < T1W

@@ -347,6 +347,17 @@ bool own_row_passes(const Geom &g)
     return !off && rowfft_supported(g);
 }
 
+// Several coefficient columns: column-innermost passes (no planar copy, no layout transposes) for chunks of at least two
+// groups of planes; NFFT_HIP_COL_PLANAR=1 keeps the planar passes + transposes of rounds 1-2.
+bool column_innermost(const Geom &g, int64_t C, int64_t nplanes)
+{
+    static const bool off = [] {
+        const char *env = std::getenv("NFFT_HIP_COL_PLANAR");
+        return env && env[0] == '1';
+    }();
+    return !off && C > 1 && nplanes >= 32 && colfft_ci_supported(g);
+}
+
 bool colfft_enabled()
 {
     const char *env = std::getenv("NFFT_HIP_NO_COLFFT");
@@ -369,6 +380,7 @@ int make_carve(const nfft_hip_problem *p, int planes_per_col, bool need_xs, FftK
     c.colfft = colfft_supported(c.g) && colfft_enabled();
     const FftKind fkind = c.colfft ? (kind == kR2C ? kR2CRows : kC2RRows) : kind;
     const int64_t plane_bytes = c.g.cells * 4 + c.half_cells * 8 + (c.colfft ? colfft_scratch_bytes(c.g, 1) : 0);
+    // (the budget is a soft one: the group padding of the column-innermost passes, <= 15 planes of scratch, comes on top)
     int64_t chunk = grid_budget_bytes() / plane_bytes;
     chunk -= chunk % planes_per_col;
     if (chunk < planes_per_col) chunk = planes_per_col;
@@ -394,7 +406,8 @@ int make_carve(const nfft_hip_problem *p, int planes_per_col, bool need_xs, FftK
     c.off_xmax = o; o = align_up(o + (need_xs ? c.total_planes * 4 : 0), 256);
     c.off_grid = o; o = align_up(o + chunk * c.g.cells * 4, 256);
     c.off_spec = o; o = align_up(o + chunk * c.half_cells * 8, 256);
-    c.off_col = o;  o = align_up(o + (c.colfft ? colfft_scratch_bytes(c.g, chunk) : 0), 256);
+    // (several columns: the column-innermost passes work on whole groups of 16 planes)
+    c.off_col = o;  o = align_up(o + (c.colfft ? colfft_scratch_bytes(c.g, c.C > 1 ? colfft_ci_planes(chunk) : chunk) : 0), 256);
     c.off_work = o; o = align_up(o + c.work_bytes, 256);
     c.total = o + 256;
     return 0;
@@ -555,6 +568,14 @@ static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64
         if (int rc = spread_any(gs, Ls, plan_s, fused ? (const float *)x : nullptr, xs, xmax, c.n, c.Cr, p0, np, grid, s)) return rc;
         if (c.colfft) {
             const bool own_rows = own_row_passes(c.g);
+            if (own_rows && column_innermost(c.g, c.C, np)) {
+                // several columns: the planes travel in groups of 16, plane index innermost, and the last pass writes the
+                // reference's [B, N^3, C] layout directly
+                { StageTimer t(kStageFft, s); if (int rc = launch_row_r2c_ci(c.g, grid, np, spec, s)) return rc; }
+                StageTimer t(kStageDeconv, s);
+                if (int rc = launch_colfft_adjoint_ci(c.g, spec, ws + c.off_col, c.C, x_is_complex, real_output, p0, np, y, mult, mult_kind, s)) return rc;
+                continue;
+            }
             if (own_rows) { StageTimer t(kStageFft, s); if (int rc = launch_row_r2c(c.g, grid, ws + c.off_col, c.chunk_planes, np, spec, s)) return rc; }
             else { StageTimer t(kStageFft, s); if (int rc = fft_execute(kR2CRows, c.g.dim, c.g.M, np, grid, spec, work, c.work_bytes, s)) return rc; }
             if (c.C > 1) {
@@ -606,18 +627,23 @@ static int forward_impl(const nfft_hip_problem *p, const float *pos, const int64
         const int64_t np = std::min(c.chunk_planes, c.total_planes - p0);
         if (c.colfft) {
             const bool own_rows = own_row_passes(c.g);
-            if (c.C > 1) {
-                // several columns: planar copy of this chunk's columns first (the grid buffer is free until the row pass)
-                StageTimer t(kStageDeconv, s);
-                const int64_t K = c.g.N * (int64_t)c.g.N * c.g.N;
-                if (int rc = launch_column_layout(false, xhat, grid, K, c.C, p0 / ppc, np / ppc, x_is_complex ? 8 : 4, s)) return rc;
-                if (int rc = launch_colfft_forward(c.g, grid, ws + c.off_col, c.chunk_planes, 1, x_is_complex, real_output, 0, np, spec, own_rows, s)) return rc;
+            if (own_rows && column_innermost(c.g, c.C, np)) {
+                { StageTimer t(kStageDeconv, s); if (int rc = launch_colfft_forward_ci(c.g, xhat, spec, ws + c.off_col, c.C, x_is_complex, real_output, p0, np, s)) return rc; }
+                { StageTimer t(kStageFft, s); if (int rc = launch_row_c2r_ci(c.g, spec, np, grid, s)) return rc; }
             } else {
-                StageTimer t(kStageDeconv, s);
-                if (int rc = launch_colfft_forward(c.g, xhat, ws + c.off_col, c.chunk_planes, c.C, x_is_complex, real_output, p0, np, spec, own_rows, s)) return rc;
+                if (c.C > 1) {
+                    // several columns: planar copy of this chunk's columns first (the grid buffer is free until the row pass)
+                    StageTimer t(kStageDeconv, s);
+                    const int64_t K = c.g.N * (int64_t)c.g.N * c.g.N;
+                    if (int rc = launch_column_layout(false, xhat, grid, K, c.C, p0 / ppc, np / ppc, x_is_complex ? 8 : 4, s)) return rc;
+                    if (int rc = launch_colfft_forward(c.g, grid, ws + c.off_col, c.chunk_planes, 1, x_is_complex, real_output, 0, np, spec, own_rows, s)) return rc;
+                } else {
+                    StageTimer t(kStageDeconv, s);
+                    if (int rc = launch_colfft_forward(c.g, xhat, ws + c.off_col, c.chunk_planes, c.C, x_is_complex, real_output, p0, np, spec, own_rows, s)) return rc;
+                }
+                if (own_rows) { StageTimer t(kStageFft, s); if (int rc = launch_row_c2r(c.g, spec, ws + c.off_col, c.chunk_planes, np, grid, s)) return rc; }
+                else { StageTimer t(kStageFft, s); if (int rc = fft_execute(kC2RRows, c.g.dim, c.g.M, np, spec, grid, work, c.work_bytes, s)) return rc; }
             }
-            if (own_rows) { StageTimer t(kStageFft, s); if (int rc = launch_row_c2r(c.g, spec, ws + c.off_col, c.chunk_planes, np, grid, s)) return rc; }
-            else { StageTimer t(kStageFft, s); if (int rc = fft_execute(kC2RRows, c.g.dim, c.g.M, np, spec, grid, work, c.work_bytes, s)) return rc; }
         } else {
             { StageTimer t(kStageDeconv, s); if (int rc = launch_deconv_forward(c.g, xhat, c.C, x_is_complex, real_output, p0, np, spec, s)) return rc; }
             { StageTimer t(kStageFft, s); if (int rc = fft_execute(kC2R, c.g.dim, c.g.M, np, spec, grid, work, c.work_bytes, s)) return rc; }

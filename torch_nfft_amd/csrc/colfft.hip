@@ -745,6 +745,326 @@ row_c2r_kernel(int KC, int KS, int64_t nrows, const float2 *__restrict__ tw, con
     }
 }
 
+// =====================================================================================================================
+// Column-innermost pipeline for several coefficient columns (C > 1).
+//
+// The reference stores spectra as [B, N^d, C] (columns innermost, docs/source/theory/dataformat.rst:43-63): the last
+// adjoint pass / first forward pass of a plane-by-plane pipeline would touch elements 8 C bytes apart, and rounds 1-2
+// therefore worked on planar copies and moved between the layouts with tiled transposes (column_layout_kernel: 17 GB of
+// the C4-share step's ~110 GB).  Here the planes of a chunk are taken in groups of kCiQ = 16 and the group index is the
+// INNERMOST index of both intermediate arrays,
+//     S'[group][u0][u1][k2][q]      (axis-2 half spectrum, kept columns only)
+//     T'[group][u0][j1][k2][q]      (after the axis-1 pass: band+ rows)
+// so that the tile of a column pass is  [M rows][16 planes]  for ONE k2: every global access is still a run of
+// 16 * 8 = 128 contiguous bytes, and the last pass writes y[b, k, c .. c + 15] -- 16 consecutive columns of one
+// frequency -- in place.  The regrouping costs no HBM traffic: the row passes, which have every plane's row in LDS
+// anyway, exchange 16 planes' rows through LDS (one wave per plane) before they write / after they read.
+constexpr int kCiQ = 16;       // planes per group (the tile width of the column passes)
+constexpr int kCiLogQ = 4;
+
+// grid rows of 16 planes -> S'.  One workgroup = 16 waves = the RP rows [row0, row0 + RP) of the 16 planes of a group.
+template <int LOGL>
+struct RowCiLds {
+    float2 tw[2 << LOGL];
+    float2 z[kCiQ][kWaveCplx];            // the waves' transform buffers; ALSO the exchange buffer
+                                          // xch[row of the round][k2][plane ^ (k2 & 15)] (RP * KC * 16 <= 16 * 512 entries),
+                                          // used while no transform is in progress: 67 KB, two workgroups per CU
+    unsigned short rev[1 << LOGL];
+};
+// slot of (row rk = rr * KC + k2, plane q) in the exchange buffer: a wave writes / reads one plane for 64 consecutive k2,
+// 128 bytes apart -- without the XOR all 64 lanes hit one pair of LDS banks
+__device__ __forceinline__ int xch_slot(int rk, int k2, int q) { return rk * kCiQ + (q ^ (k2 & (kCiQ - 1))); }
+
+template <int LOGL>
+__device__ __forceinline__ void row_ci_tables(RowCiLds<LOGL> &S, const float2 *__restrict__ tw, int tid)
+{
+    constexpr int L = 1 << LOGL, M = 2 * L;
+    for (int e = tid; e < M; e += kCiQ * 64) {
+        float2 w = tw[e & (L - 1)];
+        if (e >= L) w = make_float2(-w.x, -w.y);
+        S.tw[e] = w;
+    }
+    for (int k = tid; k < L; k += kCiQ * 64) S.rev[k] = (unsigned short)brev_row(k, LOGL);
+    __syncthreads();
+}
+
+template <int LOGL>
+__global__ void __launch_bounds__(kCiQ * 64)
+row_r2c_ci_kernel(int64_t rows_per_plane, int64_t nplanes, const float2 *__restrict__ tw, const float *__restrict__ grid,
+                  float2 *__restrict__ out)
+{
+    constexpr int L = 1 << LOGL, M = 2 * L, RP = kWaveCplx / L, KC = L / 2 + 1;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    RowCiLds<LOGL> &S = *reinterpret_cast<RowCiLds<LOGL> *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2 *z = S.z[wave];
+    row_ci_tables<LOGL>(S, tw, tid);
+    const int64_t row0 = (int64_t)blockIdx.x * RP;          // RP divides M: the rows of a round lie in one plane
+    const int64_t group = blockIdx.y;
+    const int64_t plane = group * kCiQ + wave;
+    const bool live = plane < nplanes;
+    float4 v4[kWaveCplx / 128];
+    const float4 *src4 = (const float4 *)(grid + (plane * rows_per_plane + row0) * M);
+#pragma unroll
+    for (int q = 0; q < kWaveCplx / 128; ++q) v4[q] = live ? src4[q * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < kWaveCplx / 128; ++q) {
+        const int n2 = q * 64 + lane;
+        z[zsw(2 * n2)] = make_float2(v4[q].x, v4[q].y);
+        z[zsw(2 * n2 + 1)] = make_float2(v4[q].z, v4[q].w);
+    }
+    wave_fft<false, LOGL>(z, S.tw, lane);
+    // the kept half-spectrum values of the wave's RP rows, first into registers: the exchange buffer lies over the
+    // transform buffers, which every wave must have finished reading
+    constexpr int NV = (RP * KC + 63) / 64;
+    float2 vals[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int t = i * 64 + lane;
+        vals[i] = make_float2(0.f, 0.f);
+        if (t < RP * KC) {
+            const int rr = t / KC, k = t - rr * KC;
+            const float2 a = z[zsw(rr * L + S.rev[k])];
+            float2 b = z[zsw(rr * L + S.rev[(L - k) & (L - 1)])];
+            b.y = -b.y;  // conj Z[L - k]
+            const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+            const float2 o = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
+            const float2 wo = cmul(S.tw[k], o);
+            vals[i] = make_float2(e.x + wo.y, e.y - wo.x);  // e - i w o
+        }
+    }
+    __syncthreads();
+    float2 *const xch = &S.z[0][0];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int t = i * 64 + lane;
+        if (t < RP * KC) xch[xch_slot(t, t % KC, wave)] = vals[i];
+    }
+    __syncthreads();
+    // rows row0 .. row0 + RP - 1 of S' are contiguous: RP * KC * 16 complex numbers
+    float2 *dst = out + ((group * rows_per_plane + row0) * KC) * kCiQ;
+    for (int e = tid; e < RP * KC * kCiQ; e += kCiQ * 64) {
+        const int rk = e >> kCiLogQ;
+        dst[e] = xch[xch_slot(rk, rk % KC, e & (kCiQ - 1))];
+    }
+}
+
+// S' -> grid rows of 16 planes
+template <int LOGL>
+__global__ void __launch_bounds__(kCiQ * 64)
+row_c2r_ci_kernel(int64_t rows_per_plane, int64_t nplanes, const float2 *__restrict__ tw, const float2 *__restrict__ in,
+                  float *__restrict__ grid)
+{
+    constexpr int L = 1 << LOGL, M = 2 * L, RP = kWaveCplx / L, KC = L / 2 + 1;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    RowCiLds<LOGL> &S = *reinterpret_cast<RowCiLds<LOGL> *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2 *z = S.z[wave];
+    const int64_t row0 = (int64_t)blockIdx.x * RP;
+    const int64_t group = blockIdx.y;
+    const int64_t plane = group * kCiQ + wave;
+    const float2 *src = in + ((group * rows_per_plane + row0) * KC) * kCiQ;
+    float2 *const xch = &S.z[0][0];  // (lies over the transform buffers: read out into registers before they are used)
+    for (int e = tid; e < RP * KC * kCiQ; e += kCiQ * 64) {
+        const int rk = e >> kCiLogQ;
+        xch[xch_slot(rk, rk % KC, e & (kCiQ - 1))] = src[e];
+    }
+    row_ci_tables<LOGL>(S, tw, tid);  // (ends with the barrier that also publishes xch)
+    constexpr int NIT = kWaveCplx / 64;
+    float2 va[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int n = it * 64 + lane;
+        const int rr = n >> LOGL, k = n & (L - 1);
+        const int kk = k <= L / 2 ? k : L - k;
+        va[it] = xch[xch_slot(rr * KC + kk, kk, wave)];
+    }
+    __syncthreads();
+    if (plane >= nplanes) return;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        // Z[k] = (X[k] + conj X[L-k]) + i conj(W_M^k) (X[k] - conj X[L-k]),  X = 0 beyond the band (KC = L/2 + 1: exactly
+        // one of X[k], X[L-k] is kept, both only at k = L/2 where they coincide)
+        const int n = it * 64 + lane;
+        const int k = n & (L - 1);
+        const float2 v = va[it], zero = make_float2(0.f, 0.f);
+        const float2 a = k <= L / 2 ? v : zero;
+        float2 b = k >= L / 2 ? v : zero;
+        b.y = -b.y;
+        const float2 sum = make_float2(a.x + b.x, a.y + b.y), dif = make_float2(a.x - b.x, a.y - b.y);
+        float2 w = S.tw[k];
+        w.y = -w.y;
+        const float2 wd = cmul(w, dif);
+        z[zsw(n)] = make_float2(sum.x - wd.y, sum.y + wd.x);  // sum + i w dif
+    }
+    wave_fft<true, LOGL>(z, S.tw, lane);
+    float4 *dst4 = (float4 *)(grid + (plane * rows_per_plane + row0) * M);
+#pragma unroll
+    for (int q = 0; q < kWaveCplx / 128; ++q) {
+        const int n2 = q * 64 + lane;
+        const int na = 2 * n2, nb = 2 * n2 + 1;
+        const int rr = na >> LOGL;
+        const float2 a = z[zsw(rr * L + S.rev[na & (L - 1)])], b = z[zsw(rr * L + S.rev[nb & (L - 1)])];
+        dst4[n2] = make_float4(a.x, a.y, b.x, b.y);
+    }
+}
+
+// the column passes on [M][16 planes] tiles of one k2: blockIdx = (k2, u0 or j1, group); cg.NC = 16
+__global__ void __launch_bounds__(kFftThreads)
+adj_axis1_ci_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__restrict__ S, float2 *__restrict__ T)
+{
+    extern __shared__ float2 smem[];
+    float2 *ltw = smem;
+    float2 *buf = smem + cg.M / 2;
+    const int tid = threadIdx.x;
+    const int k2 = blockIdx.x, u0 = blockIdx.y;
+    const int64_t group = blockIdx.z;
+    stage_twiddles(ltw, tw, cg.M, tid);
+    const int64_t rs = (int64_t)cg.KC * kCiQ;  // row stride of S' and T'
+    const float2 *src = S + ((group * cg.M + u0) * cg.M) * rs + (int64_t)k2 * kCiQ;
+    batched_fill<16>(cg.M << kCiLogQ, tid,
+                     [&](int idx) { return src[(int64_t)(idx >> kCiLogQ) * rs + (idx & (kCiQ - 1))]; },
+                     [&](int idx, float2 v) { buf[idx] = v; });
+    lds_fft<false>(buf, ltw, cg, tid);
+    float2 *dst = T + ((group * cg.M + u0) * cg.NB) * rs + (int64_t)k2 * kCiQ;
+    for (int idx = tid; idx < (cg.NB << kCiLogQ); idx += kFftThreads) {
+        const int q = idx & (kCiQ - 1), j1 = idx >> kCiLogQ;
+        const int k1 = (j1 - cg.H) & (cg.M - 1);
+        dst[(int64_t)j1 * rs + q] = buf[(brev_row(k1, cg.logM) << kCiLogQ) + q];
+    }
+}
+
+template <bool XCOMPLEX, bool REAL_OUT>
+__global__ void __launch_bounds__(kFftThreads)
+adj_axis0_ci_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__restrict__ T, int64_t C, int64_t plane0,
+                    int64_t nplanes, void *__restrict__ yv, const void *__restrict__ mult, int mult_kind)
+{
+    extern __shared__ float2 smem[];
+    float2 *ltw = smem;
+    float2 *buf = smem + cg.M / 2;
+    const int tid = threadIdx.x;
+    const int k2 = blockIdx.x, j1 = blockIdx.y;
+    const int64_t group = blockIdx.z;
+    stage_twiddles(ltw, tw, cg.M, tid);
+    const int64_t rs = (int64_t)cg.KC * kCiQ;
+    const float2 *src = T + (group * cg.M * cg.NB + j1) * rs + (int64_t)k2 * kCiQ;
+    batched_fill<16>(cg.M << kCiLogQ, tid,
+                     [&](int idx) { return src[(int64_t)(idx >> kCiLogQ) * cg.NB * rs + (idx & (kCiQ - 1))]; },
+                     [&](int idx, float2 v) { buf[idx] = v; });
+    lds_fft<false>(buf, ltw, cg, tid);
+
+    const int H = cg.H, N = cg.N;
+    const int k1 = j1 - H;
+    const float f12 = phi_hat_inv_f(abs(k1), cg.param) * phi_hat_inv_f(k2, cg.param);
+    constexpr int PPC = XCOMPLEX ? 2 : 1;
+    for (int idx = tid; idx < (cg.NB << kCiLogQ); idx += kFftThreads) {
+        const int q = idx & (kCiQ - 1), j0 = idx >> kCiLogQ;
+        if (XCOMPLEX && (q & 1)) continue;  // (the odd tile column is the imaginary-part plane of the column to its left)
+        const int64_t pl = group * kCiQ + q;  // plane inside the chunk
+        if (pl >= nplanes) continue;
+        const int64_t colg = (plane0 + pl) / PPC;
+        const int64_t b = colg / C, c = colg - b * C;
+        const int k0 = j0 - H;
+        const int row = (brev_row(k0 & (cg.M - 1), cg.logM) << kCiLogQ) + q;
+        const float2 fr = buf[row];
+        float2 fi = make_float2(0.f, 0.f);
+        if (XCOMPLEX) fi = buf[row + 1];
+        const float fac = phi_hat_inv_f(abs(k0), cg.param) * f12;
+        if (k0 < H && k1 < H && k2 < H) {
+            float re = (fr.x + fi.y) * fac, im = (-fr.y + fi.x) * fac;
+            const int64_t f = ((int64_t)(k0 + H) * N + (k1 + H)) * N + (k2 + H);
+            apply_mult(mult, mult_kind, f, re, im);
+            const int64_t o = (b * N * N * N + f) * C + c;
+            if (REAL_OUT) ((float *)yv)[o] = re;
+            else ((float2 *)yv)[o] = make_float2(re, im);
+        }
+        if (k2 >= 1 && k0 > -H && k1 > -H) {
+            float re = (fr.x - fi.y) * fac, im = (fr.y + fi.x) * fac;
+            const int64_t f = ((int64_t)(H - k0) * N + (H - k1)) * N + (H - k2);
+            apply_mult(mult, mult_kind, f, re, im);
+            const int64_t o = (b * N * N * N + f) * C + c;
+            if (REAL_OUT) ((float *)yv)[o] = re;
+            else ((float2 *)yv)[o] = make_float2(re, im);
+        }
+    }
+}
+
+template <bool XCOMPLEX>
+__global__ void __launch_bounds__(kFftThreads)
+fwd_axis0_ci_kernel(ColGeom cg, const float2 *__restrict__ tw, const void *__restrict__ xhat, int64_t C, int ppc,
+                    int64_t plane0, int64_t nplanes, float2 *__restrict__ T)
+{
+    extern __shared__ float2 smem[];
+    float2 *ltw = smem;
+    float2 *buf = smem + cg.M / 2;
+    const int tid = threadIdx.x;
+    const int k2 = blockIdx.x, j1 = blockIdx.y;
+    const int64_t group = blockIdx.z;
+    stage_twiddles(ltw, tw, cg.M, tid);
+    for (int idx = tid; idx < (cg.M << kCiLogQ); idx += kFftThreads) buf[idx] = make_float2(0.f, 0.f);
+    __syncthreads();
+    const int H = cg.H;
+    const int k1 = j1 - H;
+    const float f12 = 0.5f * phi_hat_inv_f(abs(k1), cg.param) * phi_hat_inv_f(k2, cg.param);
+    batched_fill<8>(cg.NB << kCiLogQ, tid,
+                    [&](int idx) {
+                        const int q = idx & (kCiQ - 1), j0 = idx >> kCiLogQ;
+                        const int64_t pl = group * kCiQ + q;
+                        if (pl >= nplanes) return make_float2(0.f, 0.f);
+                        const int64_t plane = plane0 + pl;
+                        const int64_t colg = plane / ppc;
+                        const int part = (int)(plane - colg * ppc);
+                        const int64_t b = colg / C, c = colg - b * C;
+                        const int k0 = j0 - H;
+                        const float2 ap = band_value<XCOMPLEX>(xhat, b, c, C, cg.N, H, k0, k1, k2);
+                        const float2 am = band_value<XCOMPLEX>(xhat, b, c, C, cg.N, H, -k0, -k1, -k2);
+                        const float fac = phi_hat_inv_f(abs(k0), cg.param) * f12;
+                        if (part == 0) return make_float2((am.x + ap.x) * fac, (am.y - ap.y) * fac);
+                        return make_float2((am.y + ap.y) * fac, -(am.x - ap.x) * fac);
+                    },
+                    [&](int idx, float2 v) {
+                        const int q = idx & (kCiQ - 1), j0 = idx >> kCiLogQ;
+                        buf[(((j0 - H) & (cg.M - 1)) << kCiLogQ) + q] = v;
+                    });
+    lds_fft<true>(buf, ltw, cg, tid);
+    const int64_t rs = (int64_t)cg.KC * kCiQ;
+    float2 *dst = T + (group * cg.M * cg.NB + j1) * rs + (int64_t)k2 * kCiQ;
+    for (int idx = tid; idx < (cg.M << kCiLogQ); idx += kFftThreads) {
+        const int q = idx & (kCiQ - 1), u0 = idx >> kCiLogQ;
+        dst[(int64_t)u0 * cg.NB * rs + q] = buf[(brev_row(u0, cg.logM) << kCiLogQ) + q];
+    }
+}
+
+__global__ void __launch_bounds__(kFftThreads)
+fwd_axis1_ci_kernel(ColGeom cg, const float2 *__restrict__ tw, const float2 *__restrict__ T, float2 *__restrict__ S)
+{
+    extern __shared__ float2 smem[];
+    float2 *ltw = smem;
+    float2 *buf = smem + cg.M / 2;
+    const int tid = threadIdx.x;
+    const int k2 = blockIdx.x, u0 = blockIdx.y;
+    const int64_t group = blockIdx.z;
+    stage_twiddles(ltw, tw, cg.M, tid);
+    for (int idx = tid; idx < (cg.M << kCiLogQ); idx += kFftThreads) buf[idx] = make_float2(0.f, 0.f);
+    __syncthreads();
+    const int64_t rs = (int64_t)cg.KC * kCiQ;
+    const float2 *src = T + ((group * cg.M + u0) * cg.NB) * rs + (int64_t)k2 * kCiQ;
+    batched_fill<16>(cg.NB << kCiLogQ, tid,
+                     [&](int idx) { return src[(int64_t)(idx >> kCiLogQ) * rs + (idx & (kCiQ - 1))]; },
+                     [&](int idx, float2 v) {
+                         const int q = idx & (kCiQ - 1), j1 = idx >> kCiLogQ;
+                         buf[(((j1 - cg.H) & (cg.M - 1)) << kCiLogQ) + q] = v;
+                     });
+    lds_fft<true>(buf, ltw, cg, tid);
+    float2 *dst = S + ((group * cg.M + u0) * cg.M) * rs + (int64_t)k2 * kCiQ;
+    for (int idx = tid; idx < (cg.M << kCiLogQ); idx += kFftThreads) {
+        const int q = idx & (kCiQ - 1), u1 = idx >> kCiLogQ;
+        dst[(int64_t)u1 * rs + q] = buf[(brev_row(u1, cg.logM) << kCiLogQ) + q];
+    }
+}
+
 // ---- column-interleaved <-> planar copies for several coefficient columns -------------------------------
 // The reference stores spectra as [B, N^d, C] (columns innermost).  A column pass that handles one (point set,
 // column) plane would touch elements 8 C bytes apart (measured at C = 64: the last pass twice as slow).  With C > 1
@@ -951,6 +1271,125 @@ int launch_colfft_forward(const Geom &g, const void *xhat, void *scratch, int64_
             hipLaunchKernelGGL((fwd_axis1_kernel<LM, LN>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, spec);
         }
     });
+    NFFT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---- column-innermost pipeline (several coefficient columns): launchers ---------------------------------------------
+bool colfft_ci_supported(const Geom &g) { return colfft_supported(g) && g.M >= 128 && g.M <= 1024; }
+
+// planes the buffers of a chunk of `nplanes` planes must hold in column-innermost mode (whole groups of 16)
+int64_t colfft_ci_planes(int64_t nplanes) { return (nplanes + kCiQ - 1) / kCiQ * kCiQ; }
+
+static ColGeom make_ci_geom(const Geom &g)
+{
+    ColGeom cg = make_col_geom(g, false, true);
+    cg.NC = kCiQ;
+    cg.logNC = kCiLogQ;
+    return cg;
+}
+
+template <int LOGL>
+static int launch_rows_ci_t(bool c2r, const Geom &g, int64_t nplanes, const float2 *tw, const void *in, void *out,
+                            hipStream_t stream)
+{
+    constexpr int RP = kWaveCplx >> LOGL;
+    const int64_t rows = (int64_t)g.M * g.M;
+    const dim3 blocks((unsigned)(rows / RP), (unsigned)((nplanes + kCiQ - 1) / kCiQ));
+    const size_t lds = sizeof(RowCiLds<LOGL>);
+    static DeviceOnce attr_done;
+    if (attr_done.first_use()) {
+        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)row_r2c_ci_kernel<LOGL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)row_c2r_ci_kernel<LOGL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done.mark();
+    }
+    if (c2r)
+        hipLaunchKernelGGL((row_c2r_ci_kernel<LOGL>), blocks, dim3(kCiQ * 64), lds, stream, rows, nplanes, tw, (const float2 *)in,
+                           (float *)out);
+    else
+        hipLaunchKernelGGL((row_r2c_ci_kernel<LOGL>), blocks, dim3(kCiQ * 64), lds, stream, rows, nplanes, tw, (const float *)in,
+                           (float2 *)out);
+    NFFT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int launch_rows_ci(bool c2r, const Geom &g, int64_t nplanes, const void *in, void *out, hipStream_t stream)
+{
+    if (nplanes <= 0) return 0;
+    const float2 *tw = twiddle_table(g.M);
+    if (!tw) { set_error("no twiddle table for this grid size"); return 4; }
+    switch (g.M) {
+    case 128: return launch_rows_ci_t<6>(c2r, g, nplanes, tw, in, out, stream);
+    case 256: return launch_rows_ci_t<7>(c2r, g, nplanes, tw, in, out, stream);
+    case 512: return launch_rows_ci_t<8>(c2r, g, nplanes, tw, in, out, stream);
+    case 1024: return launch_rows_ci_t<9>(c2r, g, nplanes, tw, in, out, stream);
+    }
+    set_error("row passes support M = 128 .. 1024");
+    return 1;
+}
+
+int launch_row_r2c_ci(const Geom &g, const float *grid, int64_t nplanes, float2 *spec, hipStream_t stream)
+{
+    return launch_rows_ci(false, g, nplanes, grid, spec, stream);
+}
+int launch_row_c2r_ci(const Geom &g, const float2 *spec, int64_t nplanes, float *grid, hipStream_t stream)
+{
+    return launch_rows_ci(true, g, nplanes, spec, grid, stream);
+}
+
+// S' -> T' -> y [B, N^3, C] (the planes plane0 .. plane0 + nplanes of the call), all in column-innermost order
+int launch_colfft_adjoint_ci(const Geom &g, const float2 *spec, void *scratch, int64_t C, int x_is_complex,
+                             int real_output, int64_t plane0, int64_t nplanes, void *y, const void *mult, int mult_kind,
+                             hipStream_t stream)
+{
+    if (nplanes <= 0) return 0;
+    float2 *T = (float2 *)scratch;
+    const float2 *tw = twiddle_table(g.M);
+    if (!tw) { set_error("no twiddle table for this grid size"); return 4; }
+    const ColGeom cg = make_ci_geom(g);
+    const size_t lds = col_lds_bytes(cg, false);
+    const unsigned groups = (unsigned)((nplanes + kCiQ - 1) / kCiQ);
+    allow_lds(adj_axis1_ci_kernel, lds);
+    hipLaunchKernelGGL(adj_axis1_ci_kernel, dim3(cg.KC, g.M, groups), dim3(kFftThreads), lds, stream, cg, tw, spec, T);
+    auto go = [&](auto kernel) {
+        allow_lds(kernel, lds);
+        hipLaunchKernelGGL(kernel, dim3(cg.KC, cg.NB, groups), dim3(kFftThreads), lds, stream, cg, tw, T, C, plane0, nplanes, y,
+                           mult, mult_kind);
+    };
+    if (x_is_complex) {
+        if (real_output) go(adj_axis0_ci_kernel<true, true>);
+        else go(adj_axis0_ci_kernel<true, false>);
+    } else {
+        if (real_output) go(adj_axis0_ci_kernel<false, true>);
+        else go(adj_axis0_ci_kernel<false, false>);
+    }
+    NFFT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// xhat [B, N^3, C] -> T' -> S'
+int launch_colfft_forward_ci(const Geom &g, const void *xhat, float2 *spec, void *scratch, int64_t C, int x_is_complex,
+                             int real_output, int64_t plane0, int64_t nplanes, hipStream_t stream)
+{
+    if (nplanes <= 0) return 0;
+    float2 *T = (float2 *)scratch;
+    const float2 *tw = twiddle_table(g.M);
+    if (!tw) { set_error("no twiddle table for this grid size"); return 4; }
+    const ColGeom cg = make_ci_geom(g);
+    const size_t lds = col_lds_bytes(cg, false);
+    const unsigned groups = (unsigned)((nplanes + kCiQ - 1) / kCiQ);
+    const int ppc = real_output ? 1 : 2;
+    if (x_is_complex) {
+        allow_lds(fwd_axis0_ci_kernel<true>, lds);
+        hipLaunchKernelGGL((fwd_axis0_ci_kernel<true>), dim3(cg.KC, cg.NB, groups), dim3(kFftThreads), lds, stream, cg, tw, xhat, C,
+                           ppc, plane0, nplanes, T);
+    } else {
+        allow_lds(fwd_axis0_ci_kernel<false>, lds);
+        hipLaunchKernelGGL((fwd_axis0_ci_kernel<false>), dim3(cg.KC, cg.NB, groups), dim3(kFftThreads), lds, stream, cg, tw, xhat, C,
+                           ppc, plane0, nplanes, T);
+    }
+    allow_lds(fwd_axis1_ci_kernel, lds);
+    hipLaunchKernelGGL(fwd_axis1_ci_kernel, dim3(cg.KC, g.M, groups), dim3(kFftThreads), lds, stream, cg, tw, T, spec);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -81,6 +81,19 @@ int launch_colfft_adjoint(const Geom &g, const float2 *spec, bool compact, void 
 int launch_colfft_forward(const Geom &g, const void *xhat, void *scratch, int64_t scratch_planes, int64_t C,
                           int x_is_complex, int real_output, int64_t plane0, int64_t nplanes, float2 *spec, bool compact,
                           hipStream_t stream);
+// Column-innermost pipeline for several coefficient columns (3-D, M = 128 .. 1024): the planes of a chunk travel in groups
+// of 16 with the plane index innermost in both intermediate arrays, so the last adjoint pass writes (the first forward pass
+// reads) the reference's [B, N^3, C] layout in place -- no planar copy, no transposes.  The buffers hold
+// colfft_ci_planes(nplanes) planes (whole groups).  Row passes included.
+bool colfft_ci_supported(const Geom &g);
+int64_t colfft_ci_planes(int64_t nplanes);
+int launch_row_r2c_ci(const Geom &g, const float *grid, int64_t nplanes, float2 *spec, hipStream_t stream);
+int launch_row_c2r_ci(const Geom &g, const float2 *spec, int64_t nplanes, float *grid, hipStream_t stream);
+int launch_colfft_adjoint_ci(const Geom &g, const float2 *spec, void *scratch, int64_t C, int x_is_complex,
+                             int real_output, int64_t plane0, int64_t nplanes, void *y, const void *mult, int mult_kind,
+                             hipStream_t stream);
+int launch_colfft_forward_ci(const Geom &g, const void *xhat, float2 *spec, void *scratch, int64_t C, int x_is_complex,
+                             int real_output, int64_t plane0, int64_t nplanes, hipStream_t stream);
 // planar [ncols][N^d] <-> column-interleaved [B, N^d, C] copies (tiled transposes) for the column passes with C > 1
 int launch_column_layout(bool to_interleaved, const void *src, void *dst, int64_t K, int64_t C, int64_t col0,
                          int64_t ncols, int elem_bytes, hipStream_t stream);
