@@ -92,7 +92,7 @@ def measured_traffic(kernel, workload):
     taken for this kernel, this workload and THIS kernel source (hash of the kernel's source files): after any edit
     of the kernel the figure is stale and the line says null until the PMC passes are re-run."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_spread_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_spread_traffic.json")) as f:
             t = json.load(f)
         if t.get("kernel") == kernel and t.get("workload") == workload and t.get("source_hash") == kernel_source_hash():
             return t["fetch_bytes_corrected"] + t["write_bytes"]
