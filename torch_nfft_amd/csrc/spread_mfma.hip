@@ -503,11 +503,13 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
 
     // ---- every wave adds the K-blocks that reach its plane -------------------------------------------------
     auto accumulate = [&](const MfmaOps<W> &O, const int nkb) {
-        const int slabs = O.slab[lane & (kNKB - 1)];  // one LDS read; K-block j's slab by readlane
-        const int halves = O.halves[lane & (kNKB - 1)];
+        // K-block j's slab and touched column tiles, packed into one word per lane: ONE readlane per K-block and owner (every
+        // owner walks every K-block of the batch, in or out of its window: the second readlane was 2 % of the kernel's VALU)
+        const int packed = O.slab[lane & (kNKB - 1)] * 4 + O.halves[lane & (kNKB - 1)];
         for (int j = 0; j < nkb; ++j) {
-            const int s = __builtin_amdgcn_readlane(slabs, j);
-            const int hv = __builtin_amdgcn_readlane(halves, j);
+            const int pk = __builtin_amdgcn_readlane(packed, j);
+            const int s = pk >> 2;
+            const int hv = pk & 3;
             // the sweep has passed plane myz once the current slab is beyond myz + m
             while (myz + m < s) {
                 flush();
@@ -635,9 +637,16 @@ plane_absmax_kernel(const int *__restrict__ tile_offsets, const int64_t bins_per
     __syncthreads();
     if (fixed_col) {
         const int64_t lo_al = lo - lo % Cr;  // start on a row boundary so that column = thread % Cr
-        float mx = 0.0f;
-        for (int64_t e = lo_al + threadIdx.x; e < hi; e += 256)
-            if (e >= lo) mx = fmaxf(mx, fabsf(xr[e]));
+        // four loads in flight per thread (a dependent one-load loop is latency-bound: 38 us for 40 MB at C3)
+        float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f, m3 = 0.0f;
+        int64_t e = lo_al + threadIdx.x;
+        for (; e + 768 < hi; e += 1024) {
+            const float v0 = e >= lo ? xr[e] : 0.0f, v1 = xr[e + 256], v2 = xr[e + 512], v3 = xr[e + 768];
+            m0 = fmaxf(m0, fabsf(v0)); m1 = fmaxf(m1, fabsf(v1)); m2 = fmaxf(m2, fabsf(v2)); m3 = fmaxf(m3, fabsf(v3));
+        }
+        for (; e < hi; e += 256)
+            if (e >= lo) m0 = fmaxf(m0, fabsf(xr[e]));
+        float mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
         if (Cr == 1) {
             for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
             if ((threadIdx.x & 63) == 0) atomicMax(&lmax[0], __float_as_uint(mx));
@@ -659,7 +668,7 @@ int launch_plane_absmax(const Geom &g_halo, const PlanLayout &L_halo, const void
     if (n <= 0) return 0;
     const int *to = (const int *)((const char *)plan_halo + L_halo.off_offsets);
     int64_t blocks = (n * Cr / B + 256 * 16 - 1) / (256 * 16);  // ~16 elements per thread
-    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
     hipLaunchKernelGGL(plane_absmax_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, stream, to,
                        (int64_t)g_halo.tiles_per_batch * g_halo.SB, xr, (int)Cr, xmax);
     NFFT_HIP_CHECK(hipGetLastError());
