@@ -401,8 +401,9 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
             xv = L.rawx[batch & (kXRing - 1)][st] * L.inv_xscale;
             // |x| above the plane's maximum: the batch vector is not sorted (the maxima are taken over the row range
             // of every point set).  Reported; the value is clamped so that no operand leaves the f16 range.
-            if (!(fabsf(xv) <= 1.0f)) {
-                if (xv == xv) report_fault(status, kFaultBatchOrder);  // (a NaN coefficient is the caller's business)
+            // (NaN / infinite coefficients are the caller's business: they pass through and poison their plane, as in fp32)
+            if (fabsf(xv) > 1.0f && fabsf(xv) < __builtin_huge_valf()) {
+                report_fault(status, kFaultBatchOrder);
                 xv = fminf(fmaxf(xv, -1.0f), 1.0f);
             }
         }
