@@ -203,6 +203,19 @@ __device__ __forceinline__ void split_cell(float pos, int M, int &cell, float &f
 {
     const float Mf = (float)M;
     const float hi = pos * Mf;
+    // Power-of-two M (every benchmark configuration) and an ordinary coordinate: pos * M is exact, so floor, fraction
+    // and the periodic wrap are one instruction each -- the same (cell, frac) as the general path below in 7 instead of
+    // ~25 vector instructions (three of these per point in the sort passes, in the spreading kernel's staging and in
+    // every gather block).  Anything else -- other M, |pos * M| >= 2^22, NaN -- takes the general path.
+    if ((M & (M - 1)) == 0 && fabsf(hi) < 4194304.0f) {
+        const float flp = floorf(hi);
+        const float frp = hi - flp;  // exact; == 1 only for a negative hi below half an ulp of 1 (general path: next cell)
+        if (frp < 1.0f) {
+            frac = frp;
+            cell = (int)flp & (M - 1);
+            return;
+        }
+    }
     const float lo = fmaf(pos, Mf, -hi);
     float fl = floorf(hi);
     float fr = (hi - fl) + lo;
@@ -226,6 +239,7 @@ __device__ __forceinline__ void split_cell(float pos, int M, int &cell, float &f
 
 __device__ __forceinline__ int wrap(int v, int M)
 {
+    if ((M & (M - 1)) == 0) return v & (M - 1);  // (power-of-two grids: one instruction instead of an integer modulo)
     v %= M;
     return v < 0 ? v + M : v;
 }

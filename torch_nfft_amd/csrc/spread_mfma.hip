@@ -617,18 +617,20 @@ extern "C" int nfft_dbg_set_spread_trace(void *device_buffer)
 // `xr` is the caller's row-major [point][Cr] array; the batch vector is sorted, so point set b is the row range
 // [rows[b], rows[b + 1]) with rows[b] = plan entries in front of set b in the (halo) plan.  Non-negative floats order
 // like their bit patterns, so the maxima are taken with integer atomics.
-__global__ void __launch_bounds__(256)
+constexpr int kAbsmaxThreads = 1024;
+__global__ void __launch_bounds__(kAbsmaxThreads)
 plane_absmax_kernel(const int *__restrict__ tile_offsets, const int64_t bins_per_set, const float *__restrict__ xr,
                     const int Cr, unsigned *__restrict__ xmax)
 {
-    __shared__ unsigned lmax[256];
+    __shared__ unsigned lmax[kAbsmaxThreads];
+    constexpr int NT = kAbsmaxThreads;
     const int b = blockIdx.y;
     const int64_t e0 = (int64_t)tile_offsets[b * bins_per_set] * Cr, e1 = (int64_t)tile_offsets[(b + 1) * bins_per_set] * Cr;
     const int64_t chunk = (e1 - e0 + gridDim.x - 1) / gridDim.x;
     const int64_t lo = e0 + chunk * blockIdx.x, hi = min(e1, lo + chunk);
-    const bool fixed_col = 256 % Cr == 0;  // then a thread sees one column only: e = lo' + t + 256 k
-    if (!fixed_col && Cr > 256) {
-        for (int64_t e = lo + threadIdx.x; e < hi; e += 256) {
+    const bool fixed_col = NT % Cr == 0;  // then a thread sees one column only: e = lo' + t + NT k
+    if (!fixed_col && Cr > NT) {
+        for (int64_t e = lo + threadIdx.x; e < hi; e += NT) {
             const unsigned v = __float_as_uint(fabsf(xr[e]));
             unsigned *const dst = &xmax[(int64_t)b * Cr + (int)(e % Cr)];
             if (v > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, v);
@@ -639,14 +641,14 @@ plane_absmax_kernel(const int *__restrict__ tile_offsets, const int64_t bins_per
     __syncthreads();
     if (fixed_col) {
         const int64_t lo_al = lo - lo % Cr;  // start on a row boundary so that column = thread % Cr
-        // four loads in flight per thread (a dependent one-load loop is latency-bound: 38 us for 40 MB at C3)
+        // four loads in flight per thread (a dependent one-load loop is latency-bound)
         float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f, m3 = 0.0f;
         int64_t e = lo_al + threadIdx.x;
-        for (; e + 768 < hi; e += 1024) {
-            const float v0 = e >= lo ? xr[e] : 0.0f, v1 = xr[e + 256], v2 = xr[e + 512], v3 = xr[e + 768];
+        for (; e + 3 * NT < hi; e += 4 * NT) {
+            const float v0 = e >= lo ? xr[e] : 0.0f, v1 = xr[e + NT], v2 = xr[e + 2 * NT], v3 = xr[e + 3 * NT];
             m0 = fmaxf(m0, fabsf(v0)); m1 = fmaxf(m1, fabsf(v1)); m2 = fmaxf(m2, fabsf(v2)); m3 = fmaxf(m3, fabsf(v3));
         }
-        for (; e < hi; e += 256)
+        for (; e < hi; e += NT)
             if (e >= lo) m0 = fmaxf(m0, fabsf(xr[e]));
         float mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
         if (Cr == 1) {
@@ -656,11 +658,12 @@ plane_absmax_kernel(const int *__restrict__ tile_offsets, const int64_t bins_per
             atomicMax(&lmax[threadIdx.x % Cr], __float_as_uint(mx));
         }
     } else {
-        for (int64_t e = lo + threadIdx.x; e < hi; e += 256) atomicMax(&lmax[(int)(e % Cr)], __float_as_uint(fabsf(xr[e])));
+        for (int64_t e = lo + threadIdx.x; e < hi; e += NT) atomicMax(&lmax[(int)(e % Cr)], __float_as_uint(fabsf(xr[e])));
     }
     __syncthreads();
-    // (a look before the atomic: thousands of workgroups hammering ONE word with atomicMax serialise at the L2 -- 2 441
-    // atomics cost 30 of the kernel's 40 us at C3 -- while only ~ln(workgroups) of them ever raise the maximum)
+    // Few, big workgroups: every one ends with an access to the plane's ONE word, and same-address traffic serialises at
+    // its L2 channel (measured, scripts/ubench/absmax_bench.hip: 2 442 workgroups 42 us, 1 024 22 us for the same 40 MB).
+    // A look before the atomic: only ~ln(workgroups) of them ever raise the maximum.
     if ((int)threadIdx.x < Cr && lmax[threadIdx.x]) {
         unsigned *const dst = &xmax[(int64_t)b * Cr + threadIdx.x];
         if (lmax[threadIdx.x] > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, lmax[threadIdx.x]);
@@ -674,9 +677,9 @@ int launch_plane_absmax(const Geom &g_halo, const PlanLayout &L_halo, const void
     NFFT_HIP_CHECK(hipMemsetAsync(xmax, 0, (size_t)(B * Cr * 4), stream));
     if (n <= 0) return 0;
     const int *to = (const int *)((const char *)plan_halo + L_halo.off_offsets);
-    int64_t blocks = (n * Cr / B + 256 * 16 - 1) / (256 * 16);  // ~16 elements per thread
-    blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
-    hipLaunchKernelGGL(plane_absmax_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, stream, to,
+    int64_t blocks = (n * Cr / B + kAbsmaxThreads * 32 - 1) / (kAbsmaxThreads * 32);  // ~32 elements per thread
+    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+    hipLaunchKernelGGL(plane_absmax_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(kAbsmaxThreads), 0, stream, to,
                        (int64_t)g_halo.tiles_per_batch * g_halo.SB, xr, (int)Cr, xmax);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
