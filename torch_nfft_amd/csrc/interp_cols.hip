@@ -55,7 +55,7 @@ static_assert(sizeof(IcLds) <= 160 * 1024, "LDS budget");
 
 template <int W, bool OVERFLOW>
 __global__ void __launch_bounds__(kIcThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
-interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__restrict__ perm,
+interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets,
                    const float *__restrict__ spos, const float *__restrict__ grid, const int Cr, const int64_t plane0,
                    const int64_t nplanes, const int64_t group0, float *__restrict__ yr, const int seg_slabs,
                    const int nsegm, const int *__restrict__ first_end, const int *__restrict__ order, const int4 *__restrict__ overflow)
@@ -325,7 +325,6 @@ static int launch_ic_t(const Geom &g, const PlanLayout &L, const void *plan, con
 {
     const char *base = (const char *)plan;
     const int *to = (const int *)(base + L.off_offsets);
-    const int *perm = (const int *)(base + L.off_perm);
     const float *spos = (const float *)(base + L.off_spos);
     const int *first_end = (const int *)(base + L.off_cursor);
     const int *order = (const int *)(base + L.off_order);
@@ -348,12 +347,12 @@ static int launch_ic_t(const Geom &g, const PlanLayout &L, const void *plan, con
         attr_done.mark();
     }
     const dim3 blocks((unsigned)(pencils * nsegm), (unsigned)ngroups);
-    hipLaunchKernelGGL((interp_cols_kernel<W, false>), blocks, dim3(kIcThreads), sizeof(IcLds), stream, g, to, perm, spos,
+    hipLaunchKernelGGL((interp_cols_kernel<W, false>), blocks, dim3(kIcThreads), sizeof(IcLds), stream, g, to, spos,
                        grid, (int)Cr, plane0, nplanes, group0, yr, seg_slabs, nsegm, first_end, order, (const int4 *)nullptr);
     if (L.two_level) {
         const int4 *overflow = (const int4 *)(base + L.off_tmp);
         const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)ngroups);
-        hipLaunchKernelGGL((interp_cols_kernel<W, true>), oblocks, dim3(kIcThreads), sizeof(IcLds), stream, g, to, perm,
+        hipLaunchKernelGGL((interp_cols_kernel<W, true>), oblocks, dim3(kIcThreads), sizeof(IcLds), stream, g, to,
                            spos, grid, (int)Cr, plane0, nplanes, group0, yr, seg_slabs, nsegm, first_end, order, overflow);
     }
     NFFT_HIP_CHECK(hipGetLastError());

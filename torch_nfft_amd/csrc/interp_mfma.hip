@@ -37,7 +37,7 @@ struct __align__(16) GatherMfmaLds {
 
 template <int W, bool OVERFLOW>
 __global__ void __launch_bounds__(kGmThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
-interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__restrict__ perm,
+interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets,
                    const float *__restrict__ spos, const float *__restrict__ grid, const int Cr, const int plane0,
                    float *__restrict__ yr, const int seg_slabs, const int nsegm, const int *__restrict__ first_end, const int *__restrict__ order,
                    const int4 *__restrict__ overflow)
@@ -263,7 +263,7 @@ interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const int
 bool interp_mfma_supported(const Geom &g) { return g.dim == 3 && g.wide; }
 
 template <int W>
-static int launch_gm_t(const Geom &g, const PlanLayout &L, const void *plan, const int *to, const int *perm,
+static int launch_gm_t(const Geom &g, const PlanLayout &L, const void *plan, const int *to,
                        const float *spos, const float *grid, int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes,
                        float *yr, hipStream_t stream)
 {
@@ -287,12 +287,12 @@ static int launch_gm_t(const Geom &g, const PlanLayout &L, const void *plan, con
     const int *first_end = (const int *)(base + L.off_cursor);
     const int *order = (const int *)(base + L.off_order);
     hipLaunchKernelGGL((interp_mfma_kernel<W, false>), blocks, dim3(kGmThreads), sizeof(GatherMfmaLds), stream, g, to,
-                       perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, order, (const int4 *)nullptr);
+                       spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, order, (const int4 *)nullptr);
     if (L.two_level) {
         const int4 *overflow = (const int4 *)(base + L.off_tmp);
         const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
         hipLaunchKernelGGL((interp_mfma_kernel<W, true>), oblocks, dim3(kGmThreads), sizeof(GatherMfmaLds), stream, g,
-                           to, perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, order, overflow);
+                           to, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, order, overflow);
     }
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
@@ -303,17 +303,16 @@ int launch_interp_mfma(const Geom &g, const PlanLayout &L, const void *plan, con
 {
     const char *base = (const char *)plan;
     const int *to = (const int *)(base + L.off_offsets);
-    const int *perm = (const int *)(base + L.off_perm);
     const float *spos = (const float *)(base + L.off_spos);
     if (nplanes <= 0 || n <= 0) return 0;
     switch (g.m) {
-    case 1: return launch_gm_t<4>(g, L, plan, to, perm, spos, grid, n, Cr, plane0, nplanes, yr, stream);
-    case 2: return launch_gm_t<6>(g, L, plan, to, perm, spos, grid, n, Cr, plane0, nplanes, yr, stream);
-    case 3: return launch_gm_t<8>(g, L, plan, to, perm, spos, grid, n, Cr, plane0, nplanes, yr, stream);
-    case 4: return launch_gm_t<10>(g, L, plan, to, perm, spos, grid, n, Cr, plane0, nplanes, yr, stream);
-    case 5: return launch_gm_t<12>(g, L, plan, to, perm, spos, grid, n, Cr, plane0, nplanes, yr, stream);
-    case 6: return launch_gm_t<14>(g, L, plan, to, perm, spos, grid, n, Cr, plane0, nplanes, yr, stream);
-    case 7: return launch_gm_t<16>(g, L, plan, to, perm, spos, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 1: return launch_gm_t<4>(g, L, plan, to, spos, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 2: return launch_gm_t<6>(g, L, plan, to, spos, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 3: return launch_gm_t<8>(g, L, plan, to, spos, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 4: return launch_gm_t<10>(g, L, plan, to, spos, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 5: return launch_gm_t<12>(g, L, plan, to, spos, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 6: return launch_gm_t<14>(g, L, plan, to, spos, grid, n, Cr, plane0, nplanes, yr, stream);
+    case 7: return launch_gm_t<16>(g, L, plan, to, spos, grid, n, Cr, plane0, nplanes, yr, stream);
     }
     set_error("matrix-core interpolation supports cutoff 1..7");
     return 1;

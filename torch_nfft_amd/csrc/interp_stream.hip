@@ -76,7 +76,7 @@ __device__ __forceinline__ void lds_store(int *p, int v)
 template <int W, bool OVERFLOW, int NG>
 __global__ void __launch_bounds__(kIsThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__restrict__ group_starts,
-                     const int *__restrict__ perm, const float *__restrict__ spos, const float *__restrict__ grid,
+                     const float *__restrict__ spos, const float *__restrict__ grid,
                      const int Cr, const int plane0, float *__restrict__ yr, const int seg_slabs, const int nsegm,
                      const int *__restrict__ first_end, const int *__restrict__ order, const int4 *__restrict__ overflow, int *__restrict__ status)
 {
@@ -509,7 +509,6 @@ static int launch_is_t(const Geom &g, const PlanLayout &L, const void *plan, con
     const char *base = (const char *)plan;
     const int *to = (const int *)(base + L.off_offsets);
     const int *gs = (const int *)(base + L.off_groups);
-    const int *perm = (const int *)(base + L.off_perm);
     const float *spos = (const float *)(base + L.off_spos);
     const int *first_end = (const int *)(base + L.off_cursor);
     const int *order = (const int *)(base + L.off_order);
@@ -529,12 +528,12 @@ static int launch_is_t(const Geom &g, const PlanLayout &L, const void *plan, con
         attr_done.mark();
     }
     hipLaunchKernelGGL((interp_stream_kernel<W, false, NG>), blocks, dim3(kIsThreads), sizeof(StreamLds), stream, g, to, gs,
-                       perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, order, (const int4 *)nullptr, status);
+                       spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, order, (const int4 *)nullptr, status);
     if (L.two_level) {
         const int4 *overflow = (const int4 *)(base + L.off_tmp);
         const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
         hipLaunchKernelGGL((interp_stream_kernel<W, true, NG>), oblocks, dim3(kIsThreads), sizeof(StreamLds), stream, g, to,
-                           gs, perm, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, order, overflow, status);
+                           gs, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, order, overflow, status);
     }
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;

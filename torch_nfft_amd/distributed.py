@@ -53,10 +53,6 @@ def point_bounds(batch, batch_size, world, n):
     return shard_layout(batch, world, n, batch_size)[1]
 
 
-def _batch_size(batch):
-    return 1 if batch is None else int(batch[-1].item()) + 1
-
-
 def _all_gather_rows(local, sizes, group):
     """Concatenate per-rank tensors that differ only in dim 0 (sizes known on every rank).  The result is allocated
     once and every rank's rows land in place: equal shards by one ``all_gather_into_tensor``, ragged ones by an
