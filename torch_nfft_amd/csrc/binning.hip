@@ -45,8 +45,10 @@ PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)
     L.off_hist2 = o;   o = align_up(o + (L.two_level ? L.npencils * kSort2Parts * (int64_t)g.l1bins * g.SB * g.CG * 4 : 0), 256);
     L.grouped = L.two_level && g.CG == 3;
     L.off_groups = o;  o = align_up(o + (L.grouped ? L.ntiles * 2 * 4 : 0), 256);
-    // launch order of the matrix-core kernels' work items, biggest first (wide tiling; item_order_kernel below)
-    L.off_order = o;   o = align_up(o + (g.wide ? (int64_t)g.nta[1] * g.nta[2] * B * kSegMax * 4 : 0), 256);
+    // work list of the matrix-core kernels (wide tiling; segment_split_kernel / work_order_kernel below): a header,
+    // the list and its copy in launch order.  ranges + entries / 2048 bounds the list (pieces hold >= 2048 points)
+    L.work_cap = g.wide ? (int64_t)g.nta[1] * g.nta[2] * B * kSegMax + L.cap / 2048 + 16 : 0;
+    L.off_work = o;    o = align_up(o + (g.wide ? (1 + 2 * L.work_cap) * 16 : 0), 256);
     // the count passes leave the keys they computed for the scatter passes (two bytes per point / record instead of
     // two or three more split_cell + tile-index evaluations)
     L.off_key1 = o;    o = align_up(o + (L.two_level && !g.owned ? n * 2 : 0), 256);
@@ -402,10 +404,12 @@ sort2_scatter_kernel(Geom g, int npencils, int nblocks, const int *__restrict__ 
     }
 }
 
-// Load-balance tables of the wide tiling (common.h): one wave per (point set, pencil), lane r = range r of the pencil.
+// Work list of the wide tiling (common.h): every range of slabs of every (point set, pencil), dense ranges cut
+// into pieces of about `target` points.  One wave per (point set, pencil), lane r = range r of the pencil.
+// work[0] = {entries, 1 if any range was cut, 0, 0}; entries {point set * pencils + pencil, first slab, end slab, points}.
 __global__ void __launch_bounds__(64)
 segment_split_kernel(Geom g, int npl /* point sets x pencils */, int runs, int target, const int *__restrict__ offsets,
-                     int *__restrict__ first_end /* [npl][kSegMax] */, int4 *__restrict__ overflow, int capacity)
+                     int4 *__restrict__ work, int capacity)
 {
     const int pl = blockIdx.x;
     if (pl >= npl) return;
@@ -415,13 +419,11 @@ segment_split_kernel(Geom g, int npl /* point sets x pencils */, int runs, int t
     const int seg_slabs = (g.M + runs - 1) / runs;
     const int sb = min(r * seg_slabs, g.M), se = min(sb + seg_slabs, g.M);
     const int o_sb = off[sb], pts = off[se] - o_sb;
+    if (se <= sb) return;
     int pieces = (int)(((int64_t)pts + target / 2) / target);
     pieces = pieces < 1 ? 1 : (pieces > kSegPieces ? kSegPieces : pieces);
-    int slot = 0;
-    if (pieces > 1) {
-        slot = overflow ? atomicAdd(&((int *)overflow)[0], pieces - 1) : capacity;
-        if (slot + pieces - 1 > capacity) pieces = 1;  // no room (or no list): the range stays whole
-    }
+    // (pieces <= 1 + pts / target with target >= 2048: the list's capacity, ranges + entries / 2048, always suffices)
+    if (pieces > 1) atomicOr(&((int *)work)[1], 1);
     int prev = sb;  // end of the previous piece
     for (int p = 1; p <= pieces; ++p) {
         int end = se;
@@ -434,66 +436,62 @@ segment_split_kernel(Geom g, int npl /* point sets x pencils */, int runs, int t
             }
             end = lo;
         }
-        if (p == 1) first_end[(int64_t)pl * kSegMax + r] = end;
-        else overflow[1 + slot + (p - 2)] = make_int4(pl, prev, end, 0);
+        const int piece_pts = off[end] - off[prev];
+        // (pieces without points are listed too: the owned tiling writes every plane, and the gather kernels give an
+        // item the chunks of slabs that START in it -- such a chunk may reach into the next item's slabs)
+        if (end > prev) {
+            const int slot = atomicAdd(&((int *)work)[0], 1);
+            if (slot < capacity) work[1 + slot] = make_int4(pl, prev, end, piece_pts);
+        }
         prev = end;
     }
 }
 
-// Launch order of the work items of one point set, biggest first: the kernels take item order[blockIdx.x] instead of
-// item blockIdx.x.  Workgroups are dispatched in index order, one per CU (LDS-bound), ~5.4 per CU: with the pencils in
-// grid order the last workgroups to start are as big as any and a clustered input leaves most CUs idle behind its few
-// heavy ranges (measured at C3-clustered: 43 % CU utilisation over the primary launch).  Longest first, the tail is made
-// of the small items.  A STABLE counting sort into 16 size classes (sixteenths of the largest item): items of one
-// class keep their grid order.  Balanced inputs (largest item < 1.5 x the mean item: every uniform input) keep the grid
-// order altogether: neighbouring ranges then run side by side, which measured 1 % faster at config C3 than any sorted
-// order, while the clustered C3 gains 17 % from the sorted one (profiles/r03_experiments.md).  One workgroup per point set.
+// Decides how the matrix-core kernels walk the work of this plan and, when it is the list, puts it in launch order.
+//   balanced input (no range was cut and the largest range holds < 1.5 x the mean over ALL ranges, empty ones included:
+//   every uniform input): work[0].z = 0 -- one workgroup per range in grid order, straight-line code (neighbouring
+//   ranges run side by side; measured 1 % faster at config C3 than any sorted order);
+//   otherwise work[0].z = 1 -- ONE persistent launch walks `sorted`, the list biggest first (a counting sort into 16
+//   size classes, sixteenths of the largest entry), so that the tail of the launch is made of small items.  Clustered
+//   inputs leave most CUs idle behind their few heavy ranges in grid order (43 % CU utilisation at C3-clustered), and a
+//   separate launch for the cut-off pieces (rounds 2-3) started only when the last first piece was done.
+// One workgroup.
 constexpr int kOrderClasses = 16;
 __global__ void __launch_bounds__(1024)
-item_order_kernel(Geom g, int pencils, int runs, const int *__restrict__ offsets, const int *__restrict__ first_end,
-                  int *__restrict__ order /* [set][pencils * runs] */)
+work_order_kernel(int4 *__restrict__ work, int4 *__restrict__ sorted, int capacity, int nranges)
 {
-    __shared__ int cnt[kOrderClasses][1024];  // [class][thread]: items of the class in the thread's chunk -> their first slot
+    __shared__ int cnt[kOrderClasses][1024];  // [class][thread]: entries of the class in the thread's chunk -> their first slot
     __shared__ int total[kOrderClasses];
     __shared__ int maxpts;
     __shared__ unsigned long long sumpts;
-    const int b = blockIdx.x;
-    const int nitems = pencils * runs;
-    const int seg_slabs = (g.M + runs - 1) / runs;
-    auto points = [&](const int it) {
-        const int pencil = it / runs, seg = it - pencil * runs;
-        const int sb = min(seg * seg_slabs, g.M);
-        if (sb >= g.M) return 0;
-        const int64_t pl = (int64_t)b * pencils + pencil;
-        const int *off = offsets + pl * g.np0;
-        return off[first_end[pl * kSegMax + seg]] - off[sb];
-    };
+    const int4 hdr = work[0];
+    const int nitems = min(hdr.x, capacity);
+    const int4 *list = work + 1;
     if (threadIdx.x == 0) { maxpts = 1; sumpts = 0ull; }
     __syncthreads();
-    // thread t owns the contiguous chunk [t per, (t + 1) per) of the items
+    // thread t owns the contiguous chunk [t per, (t + 1) per) of the list
     const int per = (nitems + 1023) / 1024;
     const int lo = min(nitems, (int)threadIdx.x * per), hi = min(nitems, lo + per);
     int mx = 0;
     unsigned long long sm = 0ull;
     for (int it = lo; it < hi; ++it) {
-        const int pts = points(it);
+        const int pts = list[it].w;
         mx = max(mx, pts);
         sm += (unsigned long long)pts;
     }
     atomicMax(&maxpts, mx);
     if (sm) atomicAdd(&sumpts, sm);
     __syncthreads();
-    if ((double)maxpts * (double)nitems < 1.5 * (double)sumpts) {  // balanced: grid order
-        for (int it = lo; it < hi; ++it) order[(int64_t)b * nitems + it] = it;
-        return;
-    }
+    const bool listed = nitems > 0 && (hdr.y != 0 || (double)maxpts * (double)nranges >= 1.5 * (double)sumpts);
+    if (threadIdx.x == 0) ((int *)work)[2] = listed ? 1 : 0;
+    if (!listed) return;
     const float scale = (float)kOrderClasses / (float)maxpts;
     auto size_class = [&](const int pts) { return kOrderClasses - 1 - min(kOrderClasses - 1, (int)((float)pts * scale)); };  // 0 = biggest
     int mine[kOrderClasses];
 #pragma unroll
     for (int c = 0; c < kOrderClasses; ++c) mine[c] = 0;
     for (int it = lo; it < hi; ++it) {
-        const int c = size_class(points(it));
+        const int c = size_class(list[it].w);
 #pragma unroll
         for (int q = 0; q < kOrderClasses; ++q) mine[q] += q == c ? 1 : 0;
     }
@@ -527,13 +525,14 @@ item_order_kernel(Geom g, int pencils, int runs, const int *__restrict__ offsets
         }
     }
     for (int it = lo; it < hi; ++it) {
-        const int c = size_class(points(it));
+        const int4 e = list[it];
+        const int c = size_class(e.w);
         int s_ = 0;
 #pragma unroll
         for (int q = 0; q < kOrderClasses; ++q) {
             if (q == c) { s_ = slot[q]; slot[q] += 1; }
         }
-        order[(int64_t)b * nitems + s_] = it;
+        sorted[s_] = e;
     }
 }
 
@@ -584,19 +583,20 @@ static inline int grid_for(int64_t work, int block)
     return (int)g;
 }
 
-static void launch_segment_split(const Geom &g, int64_t n, int64_t B, const int *offsets, int *first_end,
-                                 int4 *overflow, int capacity, int *order, hipStream_t stream)
+static int launch_segment_split(const Geom &g, const PlanLayout &L, int64_t n, int64_t B, const int *offsets, int4 *work,
+                                 hipStream_t stream)
 {
     const int64_t pencils = (int64_t)g.nta[1] * g.nta[2], npl = pencils * B;
     const int ncu = device_cu_count();
     const int runs = seg_base_runs(n, B, pencils, g.M, ncu);
     const int target = (int)std::min<int64_t>(seg_target_points(n, B, ncu), int64_t(1) << 30);
-    if (npl > 0)
-        hipLaunchKernelGGL(segment_split_kernel, dim3((unsigned)npl), dim3(64), 0, stream, g, (int)npl, runs, target,
-                           offsets, first_end, overflow, capacity);
-    if (npl > 0)
-        hipLaunchKernelGGL(item_order_kernel, dim3((unsigned)B), dim3(1024), 0, stream, g, (int)pencils, runs, offsets,
-                           first_end, order);
+    NFFT_HIP_CHECK(hipMemsetAsync(work, 0, 16, stream));
+    if (npl <= 0) return 0;
+    hipLaunchKernelGGL(segment_split_kernel, dim3((unsigned)npl), dim3(64), 0, stream, g, (int)npl, runs, target, offsets,
+                       work, (int)L.work_cap);
+    hipLaunchKernelGGL(work_order_kernel, dim3(1), dim3(1024), 0, stream, work, work + 1 + L.work_cap, (int)L.work_cap,
+                       (int)(npl * runs));
+    return 0;
 }
 
 int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, const int64_t *batch, int64_t n, int64_t B,
@@ -629,12 +629,7 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
                            hscan, tmp, hist2, key2);
         hipLaunchKernelGGL(sort2_scatter_kernel, dim3(npencils, kSort2Parts), dim3(kSortThreads), 2 * lds2, stream, g,
                            npencils, nblocks, hscan, tmp, hist2, key2, offsets, (int *)(base + L.off_groups), perm, spos);
-        if (g.wide) {
-            // the record area is free now: it holds the overflow list of the load-balance split
-            NFFT_HIP_CHECK(hipMemsetAsync(tmp, 0, 16, stream));
-            launch_segment_split(g, n, B, offsets, cursor, (int4 *)tmp, (int)std::min<int64_t>(n - 1, 1 << 28),
-                                 (int *)(base + L.off_order), stream);
-        }
+        if (g.wide && launch_segment_split(g, L, n, B, offsets, (int4 *)(base + L.off_work), stream)) return 2;
         NFFT_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -654,8 +649,7 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
         hipLaunchKernelGGL(bin_fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, g, pos, batch, n, B, offsets,
                            cursor, perm, spos);
     }
-    // (no record area in this path: ranges stay whole; the cursors are no longer needed)
-    if (g.wide) launch_segment_split(g, n, B, offsets, cursor, nullptr, 0, (int *)(base + L.off_order), stream);
+    if (g.wide && launch_segment_split(g, L, n, B, offsets, (int4 *)(base + L.off_work), stream)) return 2;
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }

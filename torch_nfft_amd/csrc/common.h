@@ -311,16 +311,26 @@ __device__ __forceinline__ int sub_of_cells(const Geom &g, const int cell[3])
     return s1 * g.sb2 + s2;
 }
 
+// Entry `item` (= round * gridDim.x + blockIdx.x) of a persistent launch over the plan's sorted work list: a static
+// round robin, every other round in reverse -- the workgroup that took the biggest item of one round takes the
+// smallest of the next.  (A partial last round stays in order.)
+__device__ __forceinline__ int4 listed_item(const int4 *__restrict__ sorted, const int item, const int n_items)
+{
+    const int G = (int)gridDim.x, round = item / G;
+    const bool reverse = (round & 1) && (round + 1) * G <= n_items;
+    return sorted[reverse ? (round + 1) * G - 1 - (int)blockIdx.x : item];
+}
+
 #endif // __HIPCC__
 
 // ---- plan layout -----------------------------------------------------------
 // [ tile_offset int32[ntiles*SB+1] | cursor int32[ntiles] | perm int32[n] | spos float[n*pstride] | scan temp | sort scratch ]
-// Wide tiling, load balance of the matrix-core kernels: a pencil is swept in `runs` equal ranges of slabs (one
-// workgroup each, as many as give ~5.4 workgroups per CU for an average pencil).  Ranges that hold far more points
-// than average (clustered inputs) are cut further by point count at plan time: the workgroup of the range keeps the
-// first piece (its end slab is stored in the plan's `cursor` area, kSegMax ints per pencil), the other pieces go to
-// an overflow list in the plan's `tmp` area ([0] = {count}, then {point set * pencils + pencil, first slab, end
-// slab, 0}) that a second, persistent launch walks.
+// Wide tiling, load balance of the matrix-core kernels: a pencil is swept in `runs` equal ranges of slabs (as many as
+// give ~5.4 workgroups per CU for an average pencil).  Balanced inputs (every uniform one) run one workgroup per range.
+// Ranges that hold far more points than average (clustered inputs) are cut further by point count at plan time, and all
+// pieces go to a work list in the plan ([0] = {entries, any range cut, 1 = walk the list, 0}, then {point set
+// * pencils + pencil, first slab, end slab, points}, then the same entries biggest first) that ONE persistent launch
+// walks instead.  Both launches are always enqueued; the one that is not the plan's returns at once.
 constexpr int kSegMax = 32;      // most ranges per pencil
 constexpr int kSegPieces = 16;   // most pieces a range is cut into
 inline int64_t seg_target_points(int64_t n, int64_t nsets, int ncu)
@@ -361,7 +371,7 @@ struct PlanLayout {
     int64_t off_offsets, off_cursor, off_perm, off_spos, off_scan, scan_bytes;
     int64_t off_hist, off_hscan, off_tmp, off_hist2;
     int64_t off_groups;  // column-group starts (two ints per plan bin) when `grouped`
-    int64_t off_order;   // wide tiling: work items of every point set in launch order, biggest first (binning.hip)
+    int64_t off_work, work_cap;  // wide tiling: work list {header, work_cap entries, work_cap entries in launch order} (binning.hip)
     int64_t off_key1, off_key2;  // sort scratch: first-level bin of every point, fine key of every record (16 bits each)
     bool grouped;        // the plan is ordered by column group inside the slabs (Geom::CG == 3, two-level sort)
     int64_t total;

@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(kIcThreads) __attribute__((amdgpu_waves_per_eu
 interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets,
                    const float *__restrict__ spos, const float *__restrict__ grid, const int Cr, const int64_t plane0,
                    const int64_t nplanes, const int64_t group0, float *__restrict__ yr, const int seg_slabs,
-                   const int nsegm, const int *__restrict__ first_end, const int *__restrict__ order, const int4 *__restrict__ overflow)
+                   const int nsegm, const int4 *__restrict__ work, const int4 *__restrict__ sorted)
 {
     constexpr int m = W / 2 - 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -82,22 +82,23 @@ interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets,
     const int pencils = g.nta[1] * g.nta[2];
     const int M = g.M;
 
-    const int n_items = OVERFLOW ? overflow[0].x : 1;
+    // (work items as in spread_mfma.hip: one workgroup per range, or a persistent grid over the plan's work list)
+    const int listed = work[0].z;
+    if (OVERFLOW ? !listed : listed) return;
+    const int n_items = OVERFLOW ? work[0].x : 1;
     for (int item = OVERFLOW ? (int)blockIdx.x : 0; item < n_items; item += OVERFLOW ? (int)gridDim.x : 1) {
     int pencil, sb, se;
     if constexpr (OVERFLOW) {
-        const int4 it = overflow[1 + item];
+        const int4 it = listed_item(sorted, item, n_items);
         if (it.x / pencils != b) continue;  // another point set's piece
         pencil = it.x % pencils;
         sb = it.y;
         se = it.z;
     } else {
-        // (items in the plan's launch order, biggest first: the tail of the launch is made of the small ones)
-        const int bx = order[(int64_t)b * gridDim.x + blockIdx.x];
-        pencil = bx / nsegm;
-        const int seg = bx - pencil * nsegm;
+        pencil = (int)blockIdx.x / nsegm;
+        const int seg = (int)blockIdx.x - pencil * nsegm;
         sb = min(seg * seg_slabs, M);
-        se = sb < M ? first_end[(int64_t)(b * pencils + pencil) * kSegMax + seg] : sb;
+        se = min(sb + seg_slabs, M);
     }
     if (se <= sb) continue;
     const int bin0 = b * g.tiles_per_batch + pencil * g.np0;  // one plan bin per slab
@@ -326,8 +327,7 @@ static int launch_ic_t(const Geom &g, const PlanLayout &L, const void *plan, con
     const char *base = (const char *)plan;
     const int *to = (const int *)(base + L.off_offsets);
     const float *spos = (const float *)(base + L.off_spos);
-    const int *first_end = (const int *)(base + L.off_cursor);
-    const int *order = (const int *)(base + L.off_order);
+    const int4 *work = (const int4 *)(base + L.off_work), *sorted = work + 1 + L.work_cap;
     const int64_t pencils = (int64_t)g.nta[1] * g.nta[2];
     int64_t nsets = g.tiles_per_batch > 0 ? L.ntiles / g.tiles_per_batch : 1;
     if (nsets < 1) nsets = 1;
@@ -348,13 +348,11 @@ static int launch_ic_t(const Geom &g, const PlanLayout &L, const void *plan, con
     }
     const dim3 blocks((unsigned)(pencils * nsegm), (unsigned)ngroups);
     hipLaunchKernelGGL((interp_cols_kernel<W, false>), blocks, dim3(kIcThreads), sizeof(IcLds), stream, g, to, spos,
-                       grid, (int)Cr, plane0, nplanes, group0, yr, seg_slabs, nsegm, first_end, order, (const int4 *)nullptr);
-    if (L.two_level) {
-        const int4 *overflow = (const int4 *)(base + L.off_tmp);
-        const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)ngroups);
-        hipLaunchKernelGGL((interp_cols_kernel<W, true>), oblocks, dim3(kIcThreads), sizeof(IcLds), stream, g, to,
-                           spos, grid, (int)Cr, plane0, nplanes, group0, yr, seg_slabs, nsegm, first_end, order, overflow);
-    }
+                       grid, (int)Cr, plane0, nplanes, group0, yr, seg_slabs, nsegm, work, sorted);
+    // the persistent launch over the work list (unbalanced plans; its workgroups leave at once otherwise)
+    const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)ngroups);
+    hipLaunchKernelGGL((interp_cols_kernel<W, true>), oblocks, dim3(kIcThreads), sizeof(IcLds), stream, g, to,
+                       spos, grid, (int)Cr, plane0, nplanes, group0, yr, seg_slabs, nsegm, work, sorted);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -39,8 +39,7 @@ template <int W, bool OVERFLOW>
 __global__ void __launch_bounds__(kGmThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets,
                    const float *__restrict__ spos, const float *__restrict__ grid, const int Cr, const int plane0,
-                   float *__restrict__ yr, const int seg_slabs, const int nsegm, const int *__restrict__ first_end, const int *__restrict__ order,
-                   const int4 *__restrict__ overflow)
+                   float *__restrict__ yr, const int seg_slabs, const int nsegm, const int4 *__restrict__ work, const int4 *__restrict__ sorted)
 {
     constexpr int m = W / 2 - 1;
     constexpr int TC = 17 - W;
@@ -61,23 +60,24 @@ interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets,
 
     // ---- work items: the same ranges of slabs (and, for dense ranges, pieces from the plan's overflow list) as the
     // spreading kernel (spread_mfma.hip); an item owns the chunks whose first slab lies in its range.
-    const int n_items = OVERFLOW ? overflow[0].x : 1;
+    // (work items as in spread_mfma.hip: one workgroup per range, or a persistent grid over the plan's work list)
+    const int listed = work[0].z;
+    if (OVERFLOW ? !listed : listed) return;
+    const int n_items = OVERFLOW ? work[0].x : 1;
     for (int item = OVERFLOW ? (int)blockIdx.x : 0; item < n_items; item += OVERFLOW ? (int)gridDim.x : 1) {
     if (OVERFLOW && item != (int)blockIdx.x) __syncthreads();  // the previous item is done with the LDS
     int pencil, sb, se;
     if constexpr (OVERFLOW) {
-        const int4 it = overflow[1 + item];
+        const int4 it = listed_item(sorted, item, n_items);
         if (it.x / pencils != b) continue;  // another point set's piece
         pencil = it.x % pencils;
         sb = it.y;
         se = it.z;
     } else {
-        // (items in the plan's launch order, biggest first: the tail of the launch is made of the small ones)
-        const int bx = order[(int64_t)b * gridDim.x + blockIdx.x];
-        pencil = bx / nsegm;
-        const int seg = bx - pencil * nsegm;
+        pencil = (int)blockIdx.x / nsegm;
+        const int seg = (int)blockIdx.x - pencil * nsegm;
         sb = min(seg * seg_slabs, g.M);
-        se = sb < g.M ? first_end[(int64_t)(b * pencils + pencil) * kSegMax + seg] : sb;
+        se = min(sb + seg_slabs, g.M);
     }
     const int j2 = pencil % g.nta[2];
     const int j1 = pencil / g.nta[2];
@@ -284,16 +284,13 @@ static int launch_gm_t(const Geom &g, const PlanLayout &L, const void *plan, con
         attr_done.mark();
     }
     const char *base = (const char *)plan;
-    const int *first_end = (const int *)(base + L.off_cursor);
-    const int *order = (const int *)(base + L.off_order);
+    const int4 *work = (const int4 *)(base + L.off_work), *sorted = work + 1 + L.work_cap;
     hipLaunchKernelGGL((interp_mfma_kernel<W, false>), blocks, dim3(kGmThreads), sizeof(GatherMfmaLds), stream, g, to,
-                       spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, order, (const int4 *)nullptr);
-    if (L.two_level) {
-        const int4 *overflow = (const int4 *)(base + L.off_tmp);
-        const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
-        hipLaunchKernelGGL((interp_mfma_kernel<W, true>), oblocks, dim3(kGmThreads), sizeof(GatherMfmaLds), stream, g,
-                           to, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, order, overflow);
-    }
+                       spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, work, sorted);
+    // the persistent launch over the work list (unbalanced plans; its workgroups leave at once otherwise)
+    const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
+    hipLaunchKernelGGL((interp_mfma_kernel<W, true>), oblocks, dim3(kGmThreads), sizeof(GatherMfmaLds), stream, g,
+                       to, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, work, sorted);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(kIsThreads) __attribute__((amdgpu_waves_per_eu
 interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__restrict__ group_starts,
                      const float *__restrict__ spos, const float *__restrict__ grid,
                      const int Cr, const int plane0, float *__restrict__ yr, const int seg_slabs, const int nsegm,
-                     const int *__restrict__ first_end, const int *__restrict__ order, const int4 *__restrict__ overflow, int *__restrict__ status)
+                     const int4 *__restrict__ work, const int4 *__restrict__ sorted, int *__restrict__ status)
 {
     constexpr int m = W / 2 - 1;
     constexpr int TC = 17 - W;                                   // slabs per chunk
@@ -101,22 +101,23 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
     const int pencils = g.nta[1] * g.nta[2];
     const int M = g.M;
 
-    const int n_items = OVERFLOW ? overflow[0].x : 1;
+    // (work items as in spread_mfma.hip: one workgroup per range, or a persistent grid over the plan's work list)
+    const int listed = work[0].z;
+    if (OVERFLOW ? !listed : listed) return;
+    const int n_items = OVERFLOW ? work[0].x : 1;
     for (int item = OVERFLOW ? (int)blockIdx.x : 0; item < n_items; item += OVERFLOW ? (int)gridDim.x : 1) {
     int pencil, sb, se;
     if constexpr (OVERFLOW) {
-        const int4 it = overflow[1 + item];
+        const int4 it = listed_item(sorted, item, n_items);
         if (it.x / pencils != b) continue;  // another point set's piece
         pencil = it.x % pencils;
         sb = it.y;
         se = it.z;
     } else {
-        // (items in the plan's launch order, biggest first: the tail of the launch is made of the small ones)
-        const int bx = order[(int64_t)b * gridDim.x + blockIdx.x];
-        pencil = bx / nsegm;
-        const int seg = bx - pencil * nsegm;
+        pencil = (int)blockIdx.x / nsegm;
+        const int seg = (int)blockIdx.x - pencil * nsegm;
         sb = min(seg * seg_slabs, M);
-        se = sb < M ? first_end[(int64_t)(b * pencils + pencil) * kSegMax + seg] : sb;
+        se = min(sb + seg_slabs, M);
     }
     // an item owns the chunks whose first slab lies in its range (as in interp_mfma.hip)
     const int k_begin = (sb + TC - 1) / TC;
@@ -510,8 +511,7 @@ static int launch_is_t(const Geom &g, const PlanLayout &L, const void *plan, con
     const int *to = (const int *)(base + L.off_offsets);
     const int *gs = (const int *)(base + L.off_groups);
     const float *spos = (const float *)(base + L.off_spos);
-    const int *first_end = (const int *)(base + L.off_cursor);
-    const int *order = (const int *)(base + L.off_order);
+    const int4 *work = (const int4 *)(base + L.off_work), *sorted = work + 1 + L.work_cap;
     const int64_t pencils = (int64_t)g.nta[1] * g.nta[2];
     int64_t nsets = g.tiles_per_batch > 0 ? L.ntiles / g.tiles_per_batch : 1;
     if (nsets < 1) nsets = 1;
@@ -528,13 +528,11 @@ static int launch_is_t(const Geom &g, const PlanLayout &L, const void *plan, con
         attr_done.mark();
     }
     hipLaunchKernelGGL((interp_stream_kernel<W, false, NG>), blocks, dim3(kIsThreads), sizeof(StreamLds), stream, g, to, gs,
-                       spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, order, (const int4 *)nullptr, status);
-    if (L.two_level) {
-        const int4 *overflow = (const int4 *)(base + L.off_tmp);
-        const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
-        hipLaunchKernelGGL((interp_stream_kernel<W, true, NG>), oblocks, dim3(kIsThreads), sizeof(StreamLds), stream, g, to,
-                           gs, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, first_end, order, overflow, status);
-    }
+                       spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, work, sorted, status);
+    // the persistent launch over the work list (unbalanced plans; its workgroups leave at once otherwise)
+    const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
+    hipLaunchKernelGGL((interp_stream_kernel<W, true, NG>), oblocks, dim3(kIsThreads), sizeof(StreamLds), stream, g, to,
+                       gs, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, work, sorted, status);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }

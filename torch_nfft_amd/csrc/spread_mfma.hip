@@ -112,8 +112,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                    const float *__restrict__ xr, const float *__restrict__ xs, const int64_t xs_stride,
                    const unsigned *__restrict__ xmax, const int Cr,
                    const int plane0, float *__restrict__ grid, const int seg_slabs, const int nsegm,
-                   const int *__restrict__ first_end, const int *__restrict__ order, const int4 *__restrict__ overflow,
-                   int *__restrict__ status)
+                   const int4 *__restrict__ work, const int4 *__restrict__ sorted, int *__restrict__ status)
 {
     constexpr int m = W / 2 - 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -132,27 +131,26 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     const int cr = plane - b * Cr;
     const int pencils = g.nta[1] * g.nta[2];
 
-    // ---- work items.  Primary launch (overflow == nullptr): workgroup (pencil, range) sweeps the first piece of its
-    // range of seg_slabs slabs (all of it unless the plan cut the range because it is dense).  Overflow launch: a
-    // persistent grid walks the plan's list of the other pieces (clustered inputs; empty for uniform ones).
-    // (two instantiations: the primary one is straight-line code -- the item loop costs registers)
-    const int n_items = OVERFLOW ? overflow[0].x : 1;
+    // ---- work items (common.h).  Balanced plan: workgroup (pencil, range) sweeps its range of seg_slabs slabs,
+    // straight-line code.  Otherwise a persistent grid walks the plan's work list, biggest items first.  Both launches
+    // are enqueued; the one that is not the plan's leaves here.  (two instantiations: the item loop costs registers)
+    const int listed = work[0].z;
+    if (OVERFLOW ? !listed : listed) return;
+    const int n_items = OVERFLOW ? work[0].x : 1;
     for (int item = OVERFLOW ? (int)blockIdx.x : 0; item < n_items; item += OVERFLOW ? (int)gridDim.x : 1) {
     if (OVERFLOW && item != (int)blockIdx.x) __syncthreads();  // the previous item is done with the LDS
     int pencil, sb, se;
     if constexpr (OVERFLOW) {
-        const int4 it = overflow[1 + item];
+        const int4 it = listed_item(sorted, item, n_items);
         if (it.x / pencils != b) continue;  // another point set's piece
         pencil = it.x % pencils;
         sb = it.y;
         se = it.z;
     } else {
-        // (items in the plan's launch order, biggest first: the tail of the launch is made of the small ones)
-        const int bx = order[(int64_t)b * gridDim.x + blockIdx.x];
-        pencil = bx / nsegm;
-        const int seg = bx - pencil * nsegm;
+        pencil = (int)blockIdx.x / nsegm;
+        const int seg = (int)blockIdx.x - pencil * nsegm;
         sb = min(seg * seg_slabs, g.M);
-        se = sb < g.M ? first_end[(int64_t)(b * pencils + pencil) * kSegMax + seg] : sb;
+        se = min(sb + seg_slabs, g.M);
     }
     const int j2 = pencil % g.nta[2];
     const int j1 = pencil / g.nta[2];
@@ -708,20 +706,14 @@ static int launch_mfma_t(const Geom &g, const PlanLayout &L, const void *plan, c
         attr_done.mark();
     }
     const char *base = (const char *)plan;
-    const int *first_end = (const int *)(base + L.off_cursor);
-    const int *order = (const int *)(base + L.off_order);
+    const int4 *work = (const int4 *)(base + L.off_work), *sorted = work + 1 + L.work_cap;
     int *const status = device_status_block();
     hipLaunchKernelGGL((spread_mfma_kernel<W, false, OWNED>), blocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to,
-                       spos, xr, xs, L.cap, xmax, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, order,
-                       (const int4 *)nullptr, status);
-    if (L.two_level) {
-        // the pieces the plan cut off dense ranges (none for uniform inputs: the workgroups then leave at once)
-        const int4 *overflow = (const int4 *)(base + L.off_tmp);
-        const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
-        hipLaunchKernelGGL((spread_mfma_kernel<W, true, OWNED>), oblocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g,
-                           to, spos, xr, xs, L.cap, xmax, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, first_end, order,
-                           overflow, status);
-    }
+                       spos, xr, xs, L.cap, xmax, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, work, sorted, status);
+    // the persistent launch over the work list (unbalanced plans; its workgroups leave at once otherwise)
+    const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
+    hipLaunchKernelGGL((spread_mfma_kernel<W, true, OWNED>), oblocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to,
+                       spos, xr, xs, L.cap, xmax, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, work, sorted, status);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }
