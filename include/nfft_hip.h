@@ -96,6 +96,13 @@ int nfft_hip_forward(const nfft_hip_problem *p, const float *pos, const void *xh
                      const int64_t *batch, int real_output, void *y,
                      void *workspace, int64_t workspace_bytes, void *stream);
 
+/* 0 when the library runs this problem WITHOUT a point plan: 1-D problems whose oversampled grid (2N cells, a power of
+ * two up to 4096) fits one workgroup's LDS and whose point sets are small run nfft_hip_adjoint / nfft_hip_forward as one
+ * kernel each -- workspace may be NULL for them, and building a plan for the *_planned entry points would only add five
+ * launches.  1 otherwise (callers that transform the same points repeatedly then build the plan once).  No reference
+ * counterpart: the reference recomputes shifts and window values in every call (core_cuda.cu:188-211). */
+int nfft_hip_plan_needed(const nfft_hip_problem *p);
+
 /* The same two transforms on an existing point plan (nfft_hip_plan_points below): the plan depends only on
  * (pos, batch, N, m) and can be shared by any number of adjoint / forward calls on the same points -- the
  * reference re-derives shifts and psi in every call but reuses them when sources.is_same(targets)
@@ -187,9 +194,13 @@ int nfft_hip_interpolated_kernel_coeffs(const void *grid_values, int values_are_
  * caller's stream.  nfft_hip_profile_collect waits for the recorded events and returns, per stage, the
  * summed GPU time in milliseconds and the number of launches since the last collect.  Stage order:
  * 0 point plan (binning), 1 coefficient gather, 2 grid zero-fill, 3 spreading, 4 FFT, 5 roll-off, 6 interpolation.
- * The reference has no counterpart (it has no timers at all). */
+ * The reference has no counterpart (it has no timers at all).
+ * Two event records per stage cost 3-6 us of stream time each: ~70 us per adjoint + forward pair, which is 1-2 % of a
+ * 10^7-point step but more than half of a 10^3-point one.  nfft_hip_profile_stages restricts the timers to the stages
+ * whose bit is set (bit s = stage s; default: all), e.g. 1u << 3 times the spreading kernel alone. */
 #define NFFT_HIP_NUM_STAGES 7
 void nfft_hip_profile_enable(int enable);
+void nfft_hip_profile_stages(unsigned stage_mask);
 int nfft_hip_profile_collect(double *ms_per_stage, int64_t *launches_per_stage, int num_stages);
 
 #ifdef __cplusplus

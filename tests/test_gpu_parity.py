@@ -112,7 +112,8 @@ def _random_problem(rng, d, n, B, cols, complex_x):
 
 @pytest.mark.parametrize("d,N,m", [(1, 64, 2), (1, 32, 3), (1, 512, 4), (2, 16, 3), (2, 32, 4), (2, 64, 2),
                                    (3, 16, 4), (3, 16, 2), (3, 24, 3), (3, 32, 4), (2, 16, 6), (3, 16, 5),
-                                   (1, 64, 8), (2, 32, 8), (3, 20, 7), (2, 8, 1)])
+                                   (1, 64, 8), (2, 32, 8), (3, 20, 7), (2, 8, 1),
+                                   (1, 48, 3), (1, 100, 4), (1, 4096, 2)])  # (1-D outside the fused path: small1d.hip)
 @pytest.mark.parametrize("complex_x", [False, True])
 def test_adjoint_and_forward_vs_oracle(tn, d, N, m, complex_x):
     rng = np.random.default_rng(1000 * d + N + m)

@@ -40,7 +40,9 @@ SYMBOLS = (
     "nfft_hip_coeffs_workspace_bytes",
     "nfft_hip_gaussian_interpolated_coeffs",
     "nfft_hip_interpolated_kernel_coeffs",
+    "nfft_hip_plan_needed",
     "nfft_hip_profile_enable",
+    "nfft_hip_profile_stages",
     "nfft_hip_profile_collect",
 )
 STAGES = ("plan", "gather", "zero", "spread", "fft", "rolloff", "interp")
@@ -99,6 +101,8 @@ def load():
     for f in (lib.nfft_hip_adjoint_planned, lib.nfft_hip_forward_planned):
         f.argtypes = [P, vp, vp, ci, ci, vp, vp, i64, vp]
         f.restype = ci
+    lib.nfft_hip_plan_needed.argtypes = [P]
+    lib.nfft_hip_plan_needed.restype = ci
     lib.nfft_hip_plan_bytes.argtypes = [P]
     lib.nfft_hip_plan_bytes.restype = i64
     lib.nfft_hip_plan_points.argtypes = [P, vp, vp, vp, i64, vp]
@@ -130,6 +134,8 @@ def load():
     lib.nfft_hip_interpolated_kernel_coeffs.restype = ci
     lib.nfft_hip_profile_enable.argtypes = [ci]
     lib.nfft_hip_profile_enable.restype = None
+    lib.nfft_hip_profile_stages.argtypes = [ctypes.c_uint]
+    lib.nfft_hip_profile_stages.restype = None
     lib.nfft_hip_profile_collect.argtypes = [vp, vp, ci]
     lib.nfft_hip_profile_collect.restype = ci
     if lib.nfft_hip_abi_version() != ABI_VERSION:
@@ -159,7 +165,10 @@ def load_core():
     _core_loaded = True
 
 
-def profile_enable(on):
+def profile_enable(on, stages=None):
+    """Stage timers on / off; ``stages`` = names of the stages to time (default: all of STAGES)."""
+    mask = 0xFFFFFFFF if stages is None else sum(1 << STAGES.index(s) for s in stages)
+    load().nfft_hip_profile_stages(mask)
     load().nfft_hip_profile_enable(1 if on else 0)
 
 

@@ -28,6 +28,7 @@ void set_error(const std::string &msg) { g_last_error = msg; }
 namespace {
 struct TimedSpan { int stage; hipEvent_t start, stop; };
 std::atomic<bool> g_profile{false};
+std::atomic<unsigned> g_profile_stages{~0u};  // stages that are timed while g_profile is set (bit s = stage s)
 std::mutex g_spans_mutex;  // guards g_spans / g_free_events (the entry points may be called from several threads)
 std::vector<TimedSpan> g_spans;
 std::vector<hipEvent_t> g_free_events;
@@ -43,6 +44,7 @@ hipEvent_t get_event()
 StageTimer::StageTimer(Stage stage, hipStream_t s) : slot(-1), stream(s)
 {
     if (!g_profile.load(std::memory_order_relaxed)) return;
+    if (!((g_profile_stages.load(std::memory_order_relaxed) >> (int)stage) & 1u)) return;
     std::lock_guard<std::mutex> lock(g_spans_mutex);
     TimedSpan sp{(int)stage, get_event(), get_event()};
     (void)hipEventRecord(sp.start, stream);
@@ -314,7 +316,10 @@ bool spread_permutes(const Geom &g, int64_t Cr)
         const char *env = std::getenv("NFFT_HIP_XGATHER");
         return env && env[0] == '1';
     }();
-    return !off && spread_mfma_supported(g) && Cr <= 2;
+    if (off || Cr > 2) return false;
+    // (the LDS-tile kernel of the narrow tilings reads x through the plan's permutation as well; the opt-in register-tile
+    // kernel does not)
+    return spread_mfma_supported(g) || !(spread_reg_supported(g) && spread_reg_enabled());
 }
 
 // xs: the planar copy in plan order; xr: nullptr when the caller has filled xs, else what spread_permutes() reads;
@@ -334,7 +339,7 @@ int spread_any(const Geom &g, const PlanLayout &L, const void *plan, const float
     }
     { StageTimer t(kStageZero, s); NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(np * g.cells * 4), s)); }
     StageTimer t(kStageSpread, s);
-    return launch_spread(g, L, plan, xs, n, Cr, p0, np, grid, s);
+    return launch_spread(g, L, plan, xr, xs, n, Cr, p0, np, grid, s);
 }
 
 // own pruned row passes instead of rocFFT's for the contiguous axis (NFFT_HIP_ROCFFT_ROWS=1 keeps rocFFT)
@@ -432,6 +437,11 @@ int nfft_hip_check_status(void *stream, int synchronize)
 void nfft_hip_profile_enable(int enable)
 {
     g_profile.store(enable != 0);
+}
+
+void nfft_hip_profile_stages(unsigned stage_mask)
+{
+    g_profile_stages.store(stage_mask);
 }
 
 int nfft_hip_profile_collect(double *ms_per_stage, int64_t *launches_per_stage, int num_stages)
@@ -533,6 +543,14 @@ static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64
     if (int rc = take_pending_fault()) return rc;  // a kernel of an earlier call gave up: say so
     if (int rc = validate(p)) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (!ext_plan && small1d_supported(p)) {
+        // 1-D, grid in one workgroup's LDS: one kernel, no plan, no workspace (small1d.hip)
+        if (p->batch_size * p->num_columns == 0) return 0;
+        if (!y) { set_error("Input mismatch: y is null"); return NFFT_HIP_EINVAL; }
+        if (p->num_points > 0 && (!pos || !x)) { set_error("Input mismatch: null input"); return NFFT_HIP_EINVAL; }
+        StageTimer t(kStageSpread, s);
+        return launch_small1d_adjoint(p, pos, batch, x, x_is_complex, real_output, y, mult, mult_kind, s);
+    }
     const int ppc = x_is_complex ? 2 : 1;
     Carve c;
     if (int rc = make_carve(p, ppc, true, kR2C, c)) return rc;
@@ -605,6 +623,12 @@ static int forward_impl(const nfft_hip_problem *p, const float *pos, const int64
     if (int rc = take_pending_fault()) return rc;  // a kernel of an earlier call gave up: say so
     if (int rc = validate(p)) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (!ext_plan && small1d_supported(p)) {
+        if (p->batch_size * p->num_columns == 0 || p->num_points == 0) return 0;
+        if (!y || !pos || !xhat) { set_error("Input mismatch: null input"); return NFFT_HIP_EINVAL; }
+        StageTimer t(kStageInterp, s);
+        return launch_small1d_forward(p, pos, batch, xhat, x_is_complex, real_output, y, s);
+    }
     const int ppc = real_output ? 1 : 2;
     Carve c;
     if (int rc = make_carve(p, ppc, false, kC2R, c)) return rc;
@@ -665,6 +689,12 @@ int nfft_hip_forward(const nfft_hip_problem *p, const float *pos, const void *xh
                      void *stream)
 {
     return forward_impl(p, pos, batch, nullptr, xhat, x_is_complex, real_output, y, workspace, workspace_bytes, stream);
+}
+
+int nfft_hip_plan_needed(const nfft_hip_problem *p)
+{
+    if (validate(p)) return 1;
+    return small1d_supported(p) ? 0 : 1;
 }
 
 int nfft_hip_adjoint_planned(const nfft_hip_problem *p, const void *plan, const void *x, int x_is_complex,

@@ -13,7 +13,7 @@
 
 namespace nfft {
 
-constexpr int kSortBlockPoints = 16384; // points per workgroup in the first-level passes (long runs per bin: the
+constexpr int kSortBlockPoints = 16384; // most points per workgroup in the first-level passes (long runs per bin: the
                                         // scatter writes 16-byte records, ~18 per (workgroup, bin) at C3)
 constexpr int kSortThreads = 512;
 constexpr int kMaxPencilsLds = 8192;    // first-level bins that fit an LDS histogram
@@ -26,7 +26,13 @@ PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)
     L.cap = g.owned ? 4 * n : n;
     L.ntiles = (int64_t)g.tiles_per_batch * B * g.SB;  // (tile, sub-block) bins
     L.npencils = (int64_t)g.nta[1] * g.nta[2] * B * g.l1seg;  // first-level bins: (batch, pencil, segment)
-    L.nblocks = (n + kSortBlockPoints - 1) / kSortBlockPoints;
+    // first-level slices: 16 384 points for big inputs, smaller ones (>= 1 024) as long as that gives fewer than ~512
+    // workgroups -- at n = 10^5 seven workgroups of 16 384 took 22 + 14 us for the two passes
+    L.block_points = 1024;
+    while (L.block_points < kSortBlockPoints &&
+           (n > L.block_points * 512 || L.npencils * ((n + L.block_points - 1) / L.block_points) > (int64_t(1) << 20)))
+        L.block_points *= 2;  // (and a table of per-(bin, slice) counts that stays small next to the points)
+    L.nblocks = (n + L.block_points - 1) / L.block_points;
     L.two_level = L.npencils <= kMaxPencilsLds && L.npencils * L.nblocks < (int64_t(1) << 28) && n > 0;
     const int64_t scan_items = L.two_level ? L.npencils * L.nblocks + 1 : L.ntiles + 1;
     // hipcub's temporary storage for an int scan grows with the item count; bound it without touching the device
@@ -173,15 +179,15 @@ constexpr int kSortUnroll = 8;
 
 __global__ void __launch_bounds__(kSortThreads)
 sort1_count_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restrict__ batch, int64_t n, int64_t B,
-                   int npencils, int nblocks, int *__restrict__ hist /* [pencil][block] */,
+                   int npencils, int nblocks, int block_points, int *__restrict__ hist /* [pencil][block] */,
                    unsigned short *__restrict__ key1 /* first-level bin of every point (not for the owned tiling) */,
                    int *__restrict__ status)
 {
     extern __shared__ int lds_hist[];
     for (int i = threadIdx.x; i < npencils; i += kSortThreads) lds_hist[i] = 0;
     __syncthreads();
-    const int64_t lo = (int64_t)blockIdx.x * kSortBlockPoints;
-    const int64_t hi = min(n, lo + kSortBlockPoints);
+    const int64_t lo = (int64_t)blockIdx.x * block_points;
+    const int64_t hi = min(n, lo + block_points);
     for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)kSortThreads * kSortUnroll) {
         float c0[kSortUnroll], c1[kSortUnroll], c2[kSortUnroll];
         int64_t bb[kSortUnroll];
@@ -211,14 +217,14 @@ sort1_count_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restr
 
 __global__ void __launch_bounds__(kSortThreads)
 sort1_scatter_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restrict__ batch, int64_t n, int64_t B,
-                     int npencils, int nblocks, const int *__restrict__ hscan, const unsigned short *__restrict__ key1,
+                     int npencils, int nblocks, int block_points, const int *__restrict__ hscan, const unsigned short *__restrict__ key1,
                      float4 *__restrict__ tmp)
 {
     extern __shared__ int lds_cur[];
     for (int i = threadIdx.x; i < npencils; i += kSortThreads) lds_cur[i] = hscan[(int64_t)i * nblocks + blockIdx.x];
     __syncthreads();
-    const int64_t lo = (int64_t)blockIdx.x * kSortBlockPoints;
-    const int64_t hi = min(n, lo + kSortBlockPoints);
+    const int64_t lo = (int64_t)blockIdx.x * block_points;
+    const int64_t hi = min(n, lo + block_points);
     for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)kSortThreads * kSortUnroll) {
         float c0[kSortUnroll], c1[kSortUnroll], c2[kSortUnroll];
         int64_t bb[kSortUnroll];
@@ -616,13 +622,13 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
         const size_t lds1 = (size_t)npencils * 4;
         unsigned short *key1 = (unsigned short *)(base + L.off_key1), *key2 = (unsigned short *)(base + L.off_key2);
         hipLaunchKernelGGL(sort1_count_kernel, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
-                           npencils, nblocks, hist, key1, device_status_block());
+                           npencils, nblocks, (int)L.block_points, hist, key1, device_status_block());
         size_t scan_bytes = 0;
         NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, hist, hscan, (int)items, stream));
         if ((int64_t)scan_bytes > L.scan_bytes) { set_error("scan scratch too small"); return 2; }
         NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(base + L.off_scan, scan_bytes, hist, hscan, (int)items, stream));
         hipLaunchKernelGGL(sort1_scatter_kernel, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
-                           npencils, nblocks, hscan, key1, tmp);
+                           npencils, nblocks, (int)L.block_points, hscan, key1, tmp);
         int *hist2 = (int *)(base + L.off_hist2);
         const size_t lds2 = (size_t)g.l1bins * g.SB * g.CG * 4;
         hipLaunchKernelGGL(sort2_count_kernel, dim3(npencils, kSort2Parts), dim3(kSortThreads), lds2, stream, g, nblocks,

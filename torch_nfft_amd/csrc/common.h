@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <atomic>
 #include <string>
 
@@ -366,7 +367,7 @@ struct DeviceOnce {
 struct PlanLayout {
     int64_t cap;  // entries the plan can hold: n, or 4 n for the owned tiling (an entry per touched tile)
     int64_t ntiles;
-    int64_t npencils, nblocks;  // two-level sort geometry
+    int64_t npencils, nblocks, block_points;  // two-level sort geometry
     bool two_level;
     int64_t off_offsets, off_cursor, off_perm, off_spos, off_scan, scan_bytes;
     int64_t off_hist, off_hscan, off_tmp, off_hist2;
@@ -378,5 +379,17 @@ struct PlanLayout {
 };
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B);
+
+// LDS-tile kernels of the narrow tilings (spread.hip, interp.hip): workgroups that share one (pencil, segment, plane).
+// Enough to start about two workgroups per CU, never fewer than ~128 points per workgroup, at most 32.
+inline int point_splits(const Geom &g, const PlanLayout &L, int64_t n, int64_t nplanes)
+{
+    const int64_t blocks = (int64_t)g.nta[1] * g.nta[2] * g.nseg;
+    if (blocks <= 0 || nplanes <= 0) return 1;
+    const int64_t nsets = g.tiles_per_batch > 0 ? std::max<int64_t>(1, L.ntiles / ((int64_t)g.tiles_per_batch * g.SB)) : 1;
+    int64_t s = (2 * (int64_t)device_cu_count() + blocks * nplanes - 1) / (blocks * nplanes);
+    s = std::min(s, n / (nsets * blocks * 128));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(s, 32));
+}
 
 } // namespace nfft

@@ -278,6 +278,12 @@ at::Tensor nfft_adjoint(at::Tensor pos, at::Tensor x, c10::optional<at::Tensor> 
     const at::Tensor xc = x.contiguous();
     const nfft_hip_problem q = problem(p, C, N, m);
     c10::DeviceGuard guard(x.device());
+    if (!nfft_hip_plan_needed(&q)) {  // one fused kernel on the caller's points: no plan, no workspace
+        check_rc(nfft_hip_adjoint(&q, p.pos.data_ptr<float>(), xc.data_ptr(), real_input ? 0 : 1,
+                                  p.batch.defined() ? p.batch.data_ptr<int64_t>() : nullptr, real_output ? 1 : 0,
+                                  y.data_ptr(), nullptr, 0, stream_of(x)));
+        return y;
+    }
     const int64_t ws_bytes = nfft_hip_adjoint_workspace_bytes(&q, real_input ? 0 : 1, real_output ? 1 : 0);
     if (ws_bytes < 0) check_rc(std::string(nfft_hip_last_error()).rfind("Input mismatch", 0) == 0 ? NFFT_HIP_EINVAL : NFFT_HIP_EFFT);
     at::Tensor ws = byte_buffer(ws_bytes, x);
@@ -310,6 +316,12 @@ at::Tensor nfft_forward(at::Tensor pos, at::Tensor x, c10::optional<at::Tensor> 
     const at::Tensor xc = x.contiguous();
     const nfft_hip_problem q = problem(p, C, N, m);
     c10::DeviceGuard guard(x.device());
+    if (!nfft_hip_plan_needed(&q)) {
+        check_rc(nfft_hip_forward(&q, p.pos.data_ptr<float>(), xc.data_ptr(), real_input ? 0 : 1,
+                                  p.batch.defined() ? p.batch.data_ptr<int64_t>() : nullptr, real_output ? 1 : 0,
+                                  y.data_ptr(), nullptr, 0, stream_of(x)));
+        return y;
+    }
     const int64_t ws_bytes = nfft_hip_forward_workspace_bytes(&q, real_input ? 0 : 1, real_output ? 1 : 0);
     if (ws_bytes < 0) check_rc(std::string(nfft_hip_last_error()).rfind("Input mismatch", 0) == 0 ? NFFT_HIP_EINVAL : NFFT_HIP_EFFT);
     at::Tensor ws = byte_buffer(ws_bytes, x);

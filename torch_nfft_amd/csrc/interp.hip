@@ -90,9 +90,16 @@ interp_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__r
     // Resident plane p holds the (unwrapped) grid plane base_z + p; planes [0, have) are valid.
     int base_z = 0, have = 0;
 
+    // (few tiles: blockIdx.z splits the points of every chunk over gridDim.z workgroups, as in spread.hip)
+    const int nsplit = gridDim.z, split = blockIdx.z;
     for (int k = k_begin; k < k_end; ++k) {
         int s, e;
         chunk_range(g, tile_offsets, bin0, k, s, e);
+        if (nsplit > 1) {
+            const int span = (e - s + nsplit - 1) / nsplit;
+            s = min(e, s + split * span);
+            e = min(e, s + span);
+        }
         if (e == s) continue;
         const int want_z = k * C::TC - C::M0OFF;
         // slide the planes that are still needed down (linear LDS move in batches of `shift` planes: batch b
@@ -207,9 +214,9 @@ interp_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__r
 
 template <int DIM, int W>
 static int launch_interp_t(const Geom &g, const int *to, const int *perm, const float *spos, const float *grid,
-                           int64_t Cr, int64_t plane0, int64_t nplanes, float *yr, hipStream_t stream)
+                           int64_t Cr, int64_t plane0, int64_t nplanes, int splits, float *yr, hipStream_t stream)
 {
-    const dim3 blocks((unsigned)(g.nta[1] * g.nta[2] * g.nseg), (unsigned)nplanes);
+    const dim3 blocks((unsigned)(g.nta[1] * g.nta[2] * g.nseg), (unsigned)nplanes, (unsigned)splits);
     if constexpr (DIM == 3) {
         if (g.wide) {
             hipLaunchKernelGGL((interp_kernel<DIM, W, true>), blocks, dim3(GatherCfg<DIM, W, true>::NT), 0, stream, g, to,
@@ -226,17 +233,17 @@ static int launch_interp_t(const Geom &g, const int *to, const int *perm, const 
 
 template <int DIM>
 static int launch_interp_d(const Geom &g, const int *to, const int *perm, const float *spos, const float *grid,
-                           int64_t Cr, int64_t plane0, int64_t nplanes, float *yr, hipStream_t stream)
+                           int64_t Cr, int64_t plane0, int64_t nplanes, int splits, float *yr, hipStream_t stream)
 {
     switch (g.m) {
-    case 1: return launch_interp_t<DIM, 4>(g, to, perm, spos, grid, Cr, plane0, nplanes, yr, stream);
-    case 2: return launch_interp_t<DIM, 6>(g, to, perm, spos, grid, Cr, plane0, nplanes, yr, stream);
-    case 3: return launch_interp_t<DIM, 8>(g, to, perm, spos, grid, Cr, plane0, nplanes, yr, stream);
-    case 4: return launch_interp_t<DIM, 10>(g, to, perm, spos, grid, Cr, plane0, nplanes, yr, stream);
-    case 5: return launch_interp_t<DIM, 12>(g, to, perm, spos, grid, Cr, plane0, nplanes, yr, stream);
-    case 6: return launch_interp_t<DIM, 14>(g, to, perm, spos, grid, Cr, plane0, nplanes, yr, stream);
-    case 7: return launch_interp_t<DIM, 16>(g, to, perm, spos, grid, Cr, plane0, nplanes, yr, stream);
-    case 8: return launch_interp_t<DIM, 18>(g, to, perm, spos, grid, Cr, plane0, nplanes, yr, stream);
+    case 1: return launch_interp_t<DIM, 4>(g, to, perm, spos, grid, Cr, plane0, nplanes, splits, yr, stream);
+    case 2: return launch_interp_t<DIM, 6>(g, to, perm, spos, grid, Cr, plane0, nplanes, splits, yr, stream);
+    case 3: return launch_interp_t<DIM, 8>(g, to, perm, spos, grid, Cr, plane0, nplanes, splits, yr, stream);
+    case 4: return launch_interp_t<DIM, 10>(g, to, perm, spos, grid, Cr, plane0, nplanes, splits, yr, stream);
+    case 5: return launch_interp_t<DIM, 12>(g, to, perm, spos, grid, Cr, plane0, nplanes, splits, yr, stream);
+    case 6: return launch_interp_t<DIM, 14>(g, to, perm, spos, grid, Cr, plane0, nplanes, splits, yr, stream);
+    case 7: return launch_interp_t<DIM, 16>(g, to, perm, spos, grid, Cr, plane0, nplanes, splits, yr, stream);
+    case 8: return launch_interp_t<DIM, 18>(g, to, perm, spos, grid, Cr, plane0, nplanes, splits, yr, stream);
     }
     set_error("cutoff m must be in 1..8");
     return 1;
@@ -250,10 +257,11 @@ int launch_interp(const Geom &g, const PlanLayout &L, const void *plan, const fl
     const int *perm = (const int *)(base + L.off_perm);
     const float *spos = (const float *)(base + L.off_spos);
     if (nplanes <= 0 || n <= 0) return 0;
+    const int splits = point_splits(g, L, n, nplanes);
     switch (g.dim) {
-    case 1: return launch_interp_d<1>(g, to, perm, spos, grid, Cr, plane0, nplanes, yr, stream);
-    case 2: return launch_interp_d<2>(g, to, perm, spos, grid, Cr, plane0, nplanes, yr, stream);
-    case 3: return launch_interp_d<3>(g, to, perm, spos, grid, Cr, plane0, nplanes, yr, stream);
+    case 1: return launch_interp_d<1>(g, to, perm, spos, grid, Cr, plane0, nplanes, splits, yr, stream);
+    case 2: return launch_interp_d<2>(g, to, perm, spos, grid, Cr, plane0, nplanes, splits, yr, stream);
+    case 3: return launch_interp_d<3>(g, to, perm, spos, grid, Cr, plane0, nplanes, splits, yr, stream);
     }
     set_error("dim must be 1, 2 or 3");
     return 1;

@@ -1,5 +1,6 @@
 // Internal launch interface between the C-ABI layer (api.hip) and the kernel files.
 #pragma once
+#include "../../include/nfft_hip.h"
 #include "common.h"
 
 namespace nfft {
@@ -12,7 +13,7 @@ int launch_gather_rows(const Geom &g, const PlanLayout &L, const void *plan, int
                        float *xs, hipStream_t stream);
 
 // spread.hip: grid[p, :] += ... for local planes p in [0, nplanes); global plane plane0 + p = b * Cr + cr
-int launch_spread(const Geom &g, const PlanLayout &L, const void *plan, const float *xs, int64_t n, int64_t Cr,
+int launch_spread(const Geom &g, const PlanLayout &L, const void *plan, const float *xr, const float *xs, int64_t n, int64_t Cr,
                   int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream);
 
 // spread_reg.hip: register-tile spreading for 3-D grids (no atomics; writes every cell of the planes, so the
@@ -103,6 +104,13 @@ int launch_row_r2c(const Geom &g, const float *grid, void *scratch, int64_t scra
                    float2 *spec, hipStream_t stream);
 int launch_row_c2r(const Geom &g, const float2 *spec, void *scratch, int64_t scratch_planes, int64_t nplanes,
                    float *grid, hipStream_t stream);
+
+// small1d.hip: 1-D transforms whose oversampled grid fits one workgroup's LDS -- one kernel per direction, no point plan
+bool small1d_supported(const nfft_hip_problem *p);
+int launch_small1d_adjoint(const nfft_hip_problem *p, const float *pos, const int64_t *batch, const void *x, int x_is_complex,
+                           int real_output, void *y, const void *mult, int mult_kind, hipStream_t stream);
+int launch_small1d_forward(const nfft_hip_problem *p, const float *pos, const int64_t *batch, const void *xhat, int x_is_complex,
+                           int real_output, void *y, hipStream_t stream);
 
 // api.hip: optional per-stage GPU timing with HIP events on the caller's stream (nfft_hip_profile_*)
 enum Stage { kStagePlan = 0, kStageGather, kStageZero, kStageSpread, kStageFft, kStageDeconv, kStageInterp, kNumStages };

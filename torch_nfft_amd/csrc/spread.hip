@@ -30,8 +30,9 @@ constexpr int spread_threads() { return DIM == 3 ? 1024 : 256; }
 
 template <int DIM, int W>
 __global__ void __launch_bounds__((spread_threads<DIM>()))
-spread_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *__restrict__ spos,
-              const float *__restrict__ xs, const int64_t n, const int Cr, const int plane0, float *__restrict__ grid)
+spread_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__restrict__ perm,
+              const float *__restrict__ spos, const float *__restrict__ xr, const float *__restrict__ xs, const int64_t n,
+              const int Cr, const int plane0, float *__restrict__ grid)
 {
     using C = TapCfg<DIM, W>;
     constexpr int NT = spread_threads<DIM>();
@@ -75,7 +76,12 @@ spread_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *_
     const float c0 = (float)(m - lane);  // axis-0 tap of this lane (lanes < W)
 
     float *const gplane = grid + (int64_t)plane_local * g.cells;
+    // coefficients: the caller's row-major [point][Cr] array read through the plan's permutation (one or two real
+    // columns: no gather pass), or the planar copy in plan order
     const float *const xcol = xs + (int64_t)cr * n;
+    // A grid with few tiles (1-D, 2-D: 64 tiles at N = 128) would leave most CUs idle: blockIdx.z splits the points of
+    // every chunk over gridDim.z workgroups, whose partial tiles meet in the flush atomics.
+    const int nsplit = gridDim.z, split = blockIdx.z;
 
     // Resident plane p holds the (unwrapped) grid plane base_z + p.
     int base_z = 0;
@@ -119,6 +125,11 @@ spread_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *_
     for (int k = k_begin; k < k_end; ++k) {
         int s, e;
         chunk_range(g, tile_offsets, bin0, k, s, e);
+        if (nsplit > 1) {
+            const int span = (e - s + nsplit - 1) / nsplit;
+            s = min(e, s + split * span);
+            e = min(e, s + span);
+        }
         if (e == s) continue;
         const int want_z = k * C::TC - C::M0OFF;
         if (live && want_z != base_z) retire(min(want_z - base_z, C::NP));
@@ -136,7 +147,12 @@ spread_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *_
             float xv = 0.0f;
             if (lane < cnt) {
                 pp.load(g, spos, (int64_t)j0 + lane, tb0, tb1, tb2);
-                xv = xcol[(int64_t)j0 + lane] * norm;
+                if (xr) {
+                    const int64_t src = DIM == 3 ? __float_as_int(spos[((int64_t)j0 + lane) * 4 + 3]) : perm[(int64_t)j0 + lane];
+                    xv = xr[src * Cr + cr] * norm;
+                } else {
+                    xv = xcol[(int64_t)j0 + lane] * norm;
+                }
             } else {
                 pp.clear();
             }
@@ -171,45 +187,50 @@ spread_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *_
 }
 
 template <int DIM, int W>
-static int launch_spread_t(const Geom &g, const int *tile_offsets, const float *spos, const float *xs, int64_t n,
-                           int64_t Cr, int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream)
+static int launch_spread_t(const Geom &g, const int *tile_offsets, const int *perm, const float *spos, const float *xr,
+                           const float *xs, int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, int splits, float *grid,
+                           hipStream_t stream)
 {
-    const dim3 blocks((unsigned)(g.nta[1] * g.nta[2] * g.nseg), (unsigned)nplanes);
-    hipLaunchKernelGGL((spread_kernel<DIM, W>), blocks, dim3(spread_threads<DIM>()), 0, stream, g, tile_offsets, spos,
-                       xs, n, (int)Cr, (int)plane0, grid);
+    const dim3 blocks((unsigned)(g.nta[1] * g.nta[2] * g.nseg), (unsigned)nplanes, (unsigned)splits);
+    hipLaunchKernelGGL((spread_kernel<DIM, W>), blocks, dim3(spread_threads<DIM>()), 0, stream, g, tile_offsets, perm, spos,
+                       xr, xs, n, (int)Cr, (int)plane0, grid);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 template <int DIM>
-static int launch_spread_d(const Geom &g, const int *to, const float *spos, const float *xs, int64_t n, int64_t Cr,
-                           int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream)
+static int launch_spread_d(const Geom &g, const int *to, const int *perm, const float *spos, const float *xr, const float *xs,
+                           int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, int splits, float *grid, hipStream_t stream)
 {
     switch (g.m) {
-    case 1: return launch_spread_t<DIM, 4>(g, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 2: return launch_spread_t<DIM, 6>(g, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 3: return launch_spread_t<DIM, 8>(g, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 4: return launch_spread_t<DIM, 10>(g, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 5: return launch_spread_t<DIM, 12>(g, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 6: return launch_spread_t<DIM, 14>(g, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 7: return launch_spread_t<DIM, 16>(g, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 8: return launch_spread_t<DIM, 18>(g, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 1: return launch_spread_t<DIM, 4>(g, to, perm, spos, xr, xs, n, Cr, plane0, nplanes, splits, grid, stream);
+    case 2: return launch_spread_t<DIM, 6>(g, to, perm, spos, xr, xs, n, Cr, plane0, nplanes, splits, grid, stream);
+    case 3: return launch_spread_t<DIM, 8>(g, to, perm, spos, xr, xs, n, Cr, plane0, nplanes, splits, grid, stream);
+    case 4: return launch_spread_t<DIM, 10>(g, to, perm, spos, xr, xs, n, Cr, plane0, nplanes, splits, grid, stream);
+    case 5: return launch_spread_t<DIM, 12>(g, to, perm, spos, xr, xs, n, Cr, plane0, nplanes, splits, grid, stream);
+    case 6: return launch_spread_t<DIM, 14>(g, to, perm, spos, xr, xs, n, Cr, plane0, nplanes, splits, grid, stream);
+    case 7: return launch_spread_t<DIM, 16>(g, to, perm, spos, xr, xs, n, Cr, plane0, nplanes, splits, grid, stream);
+    case 8: return launch_spread_t<DIM, 18>(g, to, perm, spos, xr, xs, n, Cr, plane0, nplanes, splits, grid, stream);
     }
     set_error("cutoff m must be in 1..8");
     return 1;
 }
 
-int launch_spread(const Geom &g, const PlanLayout &L, const void *plan, const float *xs, int64_t n, int64_t Cr,
-                  int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream)
+// xr != nullptr: the caller's row-major [point][Cr] coefficients (read through the plan's permutation); else xs, the
+// planar copy in plan order (gather_rows)
+int launch_spread(const Geom &g, const PlanLayout &L, const void *plan, const float *xr, const float *xs, int64_t n,
+                  int64_t Cr, int64_t plane0, int64_t nplanes, float *grid, hipStream_t stream)
 {
     const char *base = (const char *)plan;
     const int *to = (const int *)(base + L.off_offsets);
+    const int *perm = (const int *)(base + L.off_perm);
     const float *spos = (const float *)(base + L.off_spos);
     if (nplanes <= 0 || n <= 0) return 0;
+    const int splits = point_splits(g, L, n, nplanes);
     switch (g.dim) {
-    case 1: return launch_spread_d<1>(g, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 2: return launch_spread_d<2>(g, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
-    case 3: return launch_spread_d<3>(g, to, spos, xs, n, Cr, plane0, nplanes, grid, stream);
+    case 1: return launch_spread_d<1>(g, to, perm, spos, xr, xs, n, Cr, plane0, nplanes, splits, grid, stream);
+    case 2: return launch_spread_d<2>(g, to, perm, spos, xr, xs, n, Cr, plane0, nplanes, splits, grid, stream);
+    case 3: return launch_spread_d<3>(g, to, perm, spos, xr, xs, n, Cr, plane0, nplanes, splits, grid, stream);
     }
     set_error("dim must be 1, 2 or 3");
     return 1;
