@@ -42,7 +42,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--bandwidth", type=int, default=256)
     ap.add_argument("--cutoff", type=int, default=4)
