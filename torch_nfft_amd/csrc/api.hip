@@ -770,6 +770,21 @@ int fastsum_impl(const nfft_hip_problem *src_in, const float *sources, const int
     if (!workspace || workspace_bytes < f.total) { set_error("workspace too small"); return NFFT_HIP_EWORKSPACE; }
     char *ws = (char *)(((uintptr_t)workspace + 255) & ~uintptr_t(255));
     hipStream_t s = (hipStream_t)stream;
+    // 1-D problems whose grid fits one workgroup's LDS: adjoint (with the kernel's coefficients folded into its roll-off)
+    // and forward transform are one fused kernel each on the caller's points -- no plans (small1d.hip)
+    const bool fused1d = own_plans && small1d_supported(src) && small1d_supported(tgt);
+    if (fused1d) {
+        if (src->num_points > 0 && !sources) { set_error("Input mismatch: sources is null"); return NFFT_HIP_EINVAL; }
+        if (!targets) { set_error("Input mismatch: targets is null"); return NFFT_HIP_EINVAL; }
+        void *band1 = ws + f.off_band;
+        if (src->num_points == 0) {
+            NFFT_HIP_CHECK(hipMemsetAsync(band1, 0, (size_t)f.band_bytes, s));
+        } else {
+            if (int rc = adjoint_impl(src, sources, source_batch, nullptr, x, x_is_complex, 0, band1, nullptr, 0, stream,
+                                      coeffs, coeffs_are_complex ? 2 : 1)) return rc;
+        }
+        return forward_impl(tgt, targets, target_batch, nullptr, band1, 1, x_is_complex ? 0 : 1, y, nullptr, 0, stream);
+    }
     if (own_plans) {
         if (src->num_points > 0 && !sources) { set_error("Input mismatch: sources is null"); return NFFT_HIP_EINVAL; }
         if (!targets) { set_error("Input mismatch: targets is null"); return NFFT_HIP_EINVAL; }

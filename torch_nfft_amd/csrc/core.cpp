@@ -367,9 +367,17 @@ at::Tensor nfft_fastsum(at::Tensor sources, at::Tensor targets, at::Tensor x, at
     const nfft_hip_problem qs = problem(ps, C, N, m, NFFT_HIP_POINTS_IN_QUARTER_BALL),
                            qt = problem(pt, C, N, m, NFFT_HIP_POINTS_IN_QUARTER_BALL);
     c10::DeviceGuard guard(x.device());
-    const int64_t ws_bytes = nfft_hip_fastsum_workspace_bytes(&qs, &qt, real_input ? 0 : 1, shared ? 1 : 0, 1);
+    const bool planned = nfft_hip_plan_needed(&qs) != 0 || nfft_hip_plan_needed(&qt) != 0;
+    const int64_t ws_bytes = nfft_hip_fastsum_workspace_bytes(&qs, &qt, real_input ? 0 : 1, shared ? 1 : 0, planned ? 1 : 0);
     if (ws_bytes < 0) check_rc(std::string(nfft_hip_last_error()).rfind("Input mismatch", 0) == 0 ? NFFT_HIP_EINVAL : NFFT_HIP_EFFT);
     at::Tensor ws = byte_buffer(ws_bytes, x);
+    if (!planned) {  // two fused kernels on the caller's points (1-D, grid in LDS): no plans
+        check_rc(nfft_hip_fastsum(&qs, ps.pos.data_ptr<float>(), ps.batch.defined() ? ps.batch.data_ptr<int64_t>() : nullptr,
+                                  &qt, pt.pos.data_ptr<float>(), pt.batch.defined() ? pt.batch.data_ptr<int64_t>() : nullptr,
+                                  xc.data_ptr(), real_input ? 0 : 1, cc.data_ptr(), real_coeffs ? 0 : 1, y.data_ptr(),
+                                  ws.data_ptr(), ws_bytes, stream_of(x)));
+        return y;
+    }
     const at::Tensor plan_s = get_plan(ps, qs);
     const at::Tensor plan_t = shared ? plan_s : get_plan(pt, qt);
     check_rc(nfft_hip_fastsum_planned(&qs, plan_s.data_ptr(), &qt, plan_t.data_ptr(), xc.data_ptr(), real_input ? 0 : 1,
