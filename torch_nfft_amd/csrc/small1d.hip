@@ -30,6 +30,7 @@ bool small1d_supported(const nfft_hip_problem *p)
     const int64_t M = 2 * p->N;
     if (M < 4 || M > kS1MaxM || (M & (M - 1)) != 0) return false;
     if (p->m < 1 || p->m > 8) return false;
+    if (p->batch_size > 65535) return false;  // (point sets are the y dimension of the launch)
     const int64_t sets = p->batch_size < 1 ? 1 : (p->batch_size > 8 ? 8 : p->batch_size);
     return p->num_points <= kS1MaxSetPoints * sets;
 }
