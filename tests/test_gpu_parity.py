@@ -516,6 +516,44 @@ print("RESULT", e1, e2)
     assert float(line[1]) < T1 and float(line[2]) < T1
 
 
+@pytest.mark.parametrize("env_extra", [{"NFFT_HIP_WORK_LIST": "1"}, {"NFFT_HIP_WORK_LIST": "1", "NFFT_HIP_STREAM_MIN": "1"},
+                                       {"NFFT_HIP_WORK_LIST": "1", "NFFT_HIP_OWNED": "0"}])
+def test_work_list_forced_on_a_uniform_input(env_extra):
+    """NFFT_HIP_WORK_LIST=1 runs every wide plan from its work list -- the persistent form of the matrix-core kernels that
+    otherwise only unbalanced inputs reach: spreading (scatter and owner-computes), the lock-step and the streamed gather, the
+    wave-per-column gather (6 columns), two point sets of different size, on a 128^3 grid against the oracle."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+import torch_nfft_amd as tn
+from torch_nfft_amd import ops
+from oracle import nfft_ref
+rng = np.random.default_rng(41)
+n, N, m = 9000, 64, 4
+pos = (rng.random((n, 3)) - 0.5).astype(np.float32)
+batch = (np.arange(n) >= n // 3).astype(np.int64)
+errs = []
+for cols in ((), (6,)):
+    x = rng.standard_normal((n,) + cols).astype(np.float32)
+    xt, pt, bt = torch.from_numpy(x).cuda(), torch.from_numpy(pos).cuda(), torch.from_numpy(batch).cuda()
+    y = tn.nfft_adjoint(xt, pt, bt, bandwidth=N, cutoff=m)
+    ref = nfft_ref.nfft_adjoint(x, pos, batch, N=N, m=m)
+    errs.append(np.linalg.norm(y.cpu().numpy() - ref) / np.linalg.norm(ref))
+    f = tn.nfft_forward(y, pt, bt, cutoff=m)
+    reff = nfft_ref.nfft_forward(y.cpu().numpy(), pos, batch, m=m)
+    errs.append(np.linalg.norm(f.cpu().numpy() - reff) / np.linalg.norm(reff))
+ops.check_status()
+print("RESULT", max(errs))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    assert float(line[1]) < T1W
+
+
 @pytest.mark.parametrize("scale", [1e-25, 1e-8, 1e12, 1e30])
 def test_input_scale_invariance(tn, scale):
     """The matrix-core kernels rescale their f16 operands by powers of two (max |x| for spreading, max |G| per plane

@@ -133,6 +133,36 @@ int *device_status_block()
     return (int *)d;
 }
 
+// Ticket counters of the persistent launches over a plan's work list (common.h: WorkTickets): a ring of 64-bit words
+// {launch number, tickets taken} per device, zeroed once.  A launch owns the 256 words of its number modulo 256 -- one per
+// plane -- and claims a word by overwriting whatever an earlier launch (256 launches ago: long finished) left there, so
+// nothing is reset between launches and the plan itself stays read-only (it may be in use on several streams).
+unsigned long long *device_ticket_ring()
+{
+    static std::mutex mutex;
+    static unsigned long long *ring[kMaxDevices] = {};
+    const int dev = current_device();
+    if (dev >= kMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(mutex);
+    if (!ring[dev]) {
+        void *p = nullptr;
+        if (hipMalloc(&p, (size_t)kTicketSlots * 8) != hipSuccess || hipMemset(p, 0, (size_t)kTicketSlots * 8) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        ring[dev] = (unsigned long long *)p;
+    }
+    return ring[dev];
+}
+
+unsigned next_launch_number()
+{
+    static std::atomic<unsigned> counter{0};
+    unsigned v = ++counter;
+    if (v == 0) v = ++counter;  // (0 is what the zeroed ring holds)
+    return v;
+}
+
 // Faults the kernels of the current device have reported since the last look: sets the error text, clears the flags and
 // returns NFFT_HIP_EKERNEL (NFFT_HIP_EINVAL for a bad batch vector); 0 when there is none.
 static int take_pending_fault()
@@ -167,6 +197,17 @@ bool column_groups_enabled()
     static const bool on = [] {
         const char *env = std::getenv("NFFT_HIP_COLGROUPS");
         return !(env && env[0] == '0');
+    }();
+    return on;
+}
+
+// NFFT_HIP_WORK_LIST=1: every wide plan is run from its work list (the persistent launch), balanced or not -- for tests
+// and for timing the two forms of the matrix-core kernels against each other
+bool work_list_forced()
+{
+    static const bool on = [] {
+        const char *env = std::getenv("NFFT_HIP_WORK_LIST");
+        return env && env[0] == '1';
     }();
     return on;
 }

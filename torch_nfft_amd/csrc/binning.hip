@@ -464,7 +464,7 @@ segment_split_kernel(Geom g, int npl /* point sets x pencils */, int runs, int t
 // One workgroup.
 constexpr int kOrderClasses = 16;
 __global__ void __launch_bounds__(1024)
-work_order_kernel(int4 *__restrict__ work, int4 *__restrict__ sorted, int capacity, int nranges)
+work_order_kernel(int4 *__restrict__ work, int4 *__restrict__ sorted, int capacity, int nranges, int forced)
 {
     __shared__ int cnt[kOrderClasses][1024];  // [class][thread]: entries of the class in the thread's chunk -> their first slot
     __shared__ int total[kOrderClasses];
@@ -488,7 +488,7 @@ work_order_kernel(int4 *__restrict__ work, int4 *__restrict__ sorted, int capaci
     atomicMax(&maxpts, mx);
     if (sm) atomicAdd(&sumpts, sm);
     __syncthreads();
-    const bool listed = nitems > 0 && (hdr.y != 0 || (double)maxpts * (double)nranges >= 1.5 * (double)sumpts);
+    const bool listed = nitems > 0 && (forced || hdr.y != 0 || (double)maxpts * (double)nranges >= 1.5 * (double)sumpts);
     if (threadIdx.x == 0) ((int *)work)[2] = listed ? 1 : 0;
     if (!listed) return;
     const float scale = (float)kOrderClasses / (float)maxpts;
@@ -601,7 +601,7 @@ static int launch_segment_split(const Geom &g, const PlanLayout &L, int64_t n, i
     hipLaunchKernelGGL(segment_split_kernel, dim3((unsigned)npl), dim3(64), 0, stream, g, (int)npl, runs, target, offsets,
                        work, (int)L.work_cap);
     hipLaunchKernelGGL(work_order_kernel, dim3(1), dim3(1024), 0, stream, work, work + 1 + L.work_cap, (int)L.work_cap,
-                       (int)(npl * runs));
+                       (int)(npl * runs), work_list_forced() ? 1 : 0);
     return 0;
 }
 

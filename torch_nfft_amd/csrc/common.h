@@ -112,6 +112,10 @@ struct Geom {
 };
 
 inline bool owned_supported(int dim, int64_t N, int64_t m);
+constexpr int kTicketPlanes = 256, kTicketLaunches = 256, kTicketSlots = kTicketPlanes * kTicketLaunches;
+unsigned long long *device_ticket_ring();  // api.hip: per-device ring of ticket words (WorkTickets below); nullptr on failure
+unsigned next_launch_number();             // api.hip: process-wide, never 0
+bool work_list_forced();       // api.hip: NFFT_HIP_WORK_LIST=1 runs every wide plan from its work list
 bool column_groups_enabled();  // api.hip: NFFT_HIP_COLGROUPS=0 turns the column-group order of the plan off
 
 inline Geom make_geom(int dim, int64_t N, int64_t m, bool owned = false)
@@ -310,6 +314,48 @@ __device__ __forceinline__ int sub_of_cells(const Geom &g, const int cell[3])
     const int s1 = (cell[1] % g.Ta[1]) / kSub;
     const int s2 = (cell[2] % g.Ta[2]) / kSub;
     return s1 * g.sb2 + s2;
+}
+
+// Dynamic hand-out of the sorted work list to the workgroups of a persistent launch: a workgroup starts with entry
+// blockIdx.x and then takes the next free entry whenever it is done (the list is sorted biggest first: longest-processing-
+// time-first scheduling).  One 64-bit word {launch number, entries handed out} per plane of the launch in the library's
+// ring (api.hip: device_ticket_ring).  A ticket is ONE atomic add; only the first arrivals of a launch, which find an
+// older launch's number in the word, claim it with a compare-and-swap (a CAS per ticket was quadratic under the
+// stampede of a launch's first round: +2.3 ms at C3-clustered).
+struct WorkTickets {
+    unsigned long long *ring;  // nullptr: static round robin (more planes than a launch's share of the ring)
+    unsigned launch;
+};
+__device__ __forceinline__ int take_ticket(const WorkTickets &t, const int plane_local)
+{
+    unsigned long long *slot = t.ring + (((t.launch & (kTicketLaunches - 1)) * kTicketPlanes) + plane_local);
+    const unsigned long long mine = (unsigned long long)t.launch << 32;
+    while (true) {
+        const unsigned long long old = atomicAdd(slot, 1ull);
+        if ((old >> 32) == t.launch) return (int)(unsigned)old;
+        // an older launch's word (plus the increment just made): install {launch, 1} and take ticket 0 -- unless another
+        // workgroup of this launch gets there first
+        unsigned long long cur = old + 1ull;
+        while ((cur >> 32) != t.launch) {
+            const unsigned long long seen = atomicCAS(slot, cur, mine | 1ull);
+            if (seen == cur) return 0;
+            cur = seen;
+        }
+    }
+}
+
+// Next entry of the work list for this workgroup of a persistent launch (n_items or more: none left): its own index
+// first, then tickets -- or the static round robin.  Called by all threads of the workgroup together; `word` is an LDS
+// int of the workgroup.
+__device__ __forceinline__ int next_work_item(const WorkTickets &t, int *word, const int prev /* < 0: first call */,
+                                              const int plane_local)
+{
+    if (prev < 0) return (int)blockIdx.x;
+    if (!t.ring) return prev + (int)gridDim.x;
+    __syncthreads();  // every wave is done with the previous item (and has read the previous ticket)
+    if (threadIdx.x == 0) *word = (int)gridDim.x + take_ticket(t, plane_local);
+    __syncthreads();
+    return *word;
 }
 
 // Entry `item` (= round * gridDim.x + blockIdx.x) of a persistent launch over the plan's sorted work list: a static

@@ -47,6 +47,7 @@ struct __align__(16) IcLds {
     IcBlock blk[kIcBlocks];                 // 130 KB
     float yacc[kIcWaves][kIcBlocks][64];    // running sums of a wave's column, per block and lane   20 KB
     int zf[kIcBlocks], zl[kIcBlocks];       // first / last plane of the block's window
+    int ticket;                             // work-list entry of the workgroup (persistent launch: next_work_item)
 };
 // after a group's sweep the block area is reused to transpose the results: [point of the group][column]
 constexpr int kIcStageStride = kIcWaves + 1;
@@ -58,7 +59,7 @@ __global__ void __launch_bounds__(kIcThreads) __attribute__((amdgpu_waves_per_eu
 interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets,
                    const float *__restrict__ spos, const float *__restrict__ grid, const int Cr, const int64_t plane0,
                    const int64_t nplanes, const int64_t group0, float *__restrict__ yr, const int seg_slabs,
-                   const int nsegm, const int4 *__restrict__ work, const int4 *__restrict__ sorted)
+                   const int nsegm, const int4 *__restrict__ work, const int4 *__restrict__ sorted, const WorkTickets tickets)
 {
     constexpr int m = W / 2 - 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -86,10 +87,11 @@ interp_cols_kernel(const Geom g, const int *__restrict__ tile_offsets,
     const int listed = work[0].z;
     if (OVERFLOW ? !listed : listed) return;
     const int n_items = OVERFLOW ? work[0].x : 1;
-    for (int item = OVERFLOW ? (int)blockIdx.x : 0; item < n_items; item += OVERFLOW ? (int)gridDim.x : 1) {
+    for (int item = OVERFLOW ? next_work_item(tickets, &L.ticket, -1, (int)blockIdx.y) : 0; item < n_items;
+         item = OVERFLOW ? next_work_item(tickets, &L.ticket, item, (int)blockIdx.y) : 1) {
     int pencil, sb, se;
     if constexpr (OVERFLOW) {
-        const int4 it = listed_item(sorted, item, n_items);
+        const int4 it = tickets.ring ? sorted[item] : listed_item(sorted, item, n_items);
         if (it.x / pencils != b) continue;  // another point set's piece
         pencil = it.x % pencils;
         sb = it.y;
@@ -348,11 +350,13 @@ static int launch_ic_t(const Geom &g, const PlanLayout &L, const void *plan, con
     }
     const dim3 blocks((unsigned)(pencils * nsegm), (unsigned)ngroups);
     hipLaunchKernelGGL((interp_cols_kernel<W, false>), blocks, dim3(kIcThreads), sizeof(IcLds), stream, g, to, spos,
-                       grid, (int)Cr, plane0, nplanes, group0, yr, seg_slabs, nsegm, work, sorted);
-    // the persistent launch over the work list (unbalanced plans; its workgroups leave at once otherwise)
+                       grid, (int)Cr, plane0, nplanes, group0, yr, seg_slabs, nsegm, work, sorted, WorkTickets{nullptr, 0u});
+    // the persistent launch over the work list (unbalanced plans; its workgroups leave at once otherwise); entries are
+    // handed out by tickets when the launch's planes fit its share of the ticket ring, else round robin
+    const WorkTickets tickets{ngroups <= kTicketPlanes ? device_ticket_ring() : nullptr, next_launch_number()};
     const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)ngroups);
     hipLaunchKernelGGL((interp_cols_kernel<W, true>), oblocks, dim3(kIcThreads), sizeof(IcLds), stream, g, to,
-                       spos, grid, (int)Cr, plane0, nplanes, group0, yr, seg_slabs, nsegm, work, sorted);
+                       spos, grid, (int)Cr, plane0, nplanes, group0, yr, seg_slabs, nsegm, work, sorted, tickets);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }

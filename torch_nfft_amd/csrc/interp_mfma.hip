@@ -33,13 +33,14 @@ struct __align__(16) GatherMfmaLds {
     f16x8 frag[kRing][4][2][64];  // [plane slot][k-step][hi/lo][lane = 32 (column half) + row]
     unsigned pmax[kRing];         // bit pattern of max |G| over the plane tile (staging)
     float pinv[kRing];            // what one unit of the scaled plane is worth, times the B operand scale
+    int ticket;                   // work-list entry of the workgroup (persistent launch: next_work_item)
 };
 
 template <int W, bool OVERFLOW>
 __global__ void __launch_bounds__(kGmThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets,
                    const float *__restrict__ spos, const float *__restrict__ grid, const int Cr, const int plane0,
-                   float *__restrict__ yr, const int seg_slabs, const int nsegm, const int4 *__restrict__ work, const int4 *__restrict__ sorted)
+                   float *__restrict__ yr, const int seg_slabs, const int nsegm, const int4 *__restrict__ work, const int4 *__restrict__ sorted, const WorkTickets tickets)
 {
     constexpr int m = W / 2 - 1;
     constexpr int TC = 17 - W;
@@ -64,11 +65,12 @@ interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets,
     const int listed = work[0].z;
     if (OVERFLOW ? !listed : listed) return;
     const int n_items = OVERFLOW ? work[0].x : 1;
-    for (int item = OVERFLOW ? (int)blockIdx.x : 0; item < n_items; item += OVERFLOW ? (int)gridDim.x : 1) {
+    for (int item = OVERFLOW ? next_work_item(tickets, &L.ticket, -1, plane_local) : 0; item < n_items;
+         item = OVERFLOW ? next_work_item(tickets, &L.ticket, item, plane_local) : 1) {
     if (OVERFLOW && item != (int)blockIdx.x) __syncthreads();  // the previous item is done with the LDS
     int pencil, sb, se;
     if constexpr (OVERFLOW) {
-        const int4 it = listed_item(sorted, item, n_items);
+        const int4 it = tickets.ring ? sorted[item] : listed_item(sorted, item, n_items);
         if (it.x / pencils != b) continue;  // another point set's piece
         pencil = it.x % pencils;
         sb = it.y;
@@ -286,11 +288,13 @@ static int launch_gm_t(const Geom &g, const PlanLayout &L, const void *plan, con
     const char *base = (const char *)plan;
     const int4 *work = (const int4 *)(base + L.off_work), *sorted = work + 1 + L.work_cap;
     hipLaunchKernelGGL((interp_mfma_kernel<W, false>), blocks, dim3(kGmThreads), sizeof(GatherMfmaLds), stream, g, to,
-                       spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, work, sorted);
-    // the persistent launch over the work list (unbalanced plans; its workgroups leave at once otherwise)
+                       spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, work, sorted, WorkTickets{nullptr, 0u});
+    // the persistent launch over the work list (unbalanced plans; its workgroups leave at once otherwise); entries are
+    // handed out by tickets when the launch's planes fit its share of the ticket ring, else round robin
+    const WorkTickets tickets{nplanes <= kTicketPlanes ? device_ticket_ring() : nullptr, next_launch_number()};
     const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
     hipLaunchKernelGGL((interp_mfma_kernel<W, true>), oblocks, dim3(kGmThreads), sizeof(GatherMfmaLds), stream, g,
-                       to, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, work, sorted);
+                       to, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, work, sorted, tickets);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }

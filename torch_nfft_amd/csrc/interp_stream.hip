@@ -57,6 +57,7 @@ struct __align__(16) StreamLds {
     int progress[kIsConsumers];      // first plane a consumer still needs
     int next_block;                  // block queue (counts in units of 64: every lane adds 1)
     int abort;                       // set when a spin loop ran out: everybody leaves
+    int ticket;                      // work-list entry of the workgroup (persistent launch: next_work_item)
     // runs of the item: run e = (slab - first slab) * NG + group
     int run_start[kIsMaxRuns + 4];   // first point of run e; [runs] = end of the last one
     int run_cum[kIsMaxRuns + 4];     // points of the same chunk and group in front of run e
@@ -78,7 +79,7 @@ __global__ void __launch_bounds__(kIsThreads) __attribute__((amdgpu_waves_per_eu
 interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const int *__restrict__ group_starts,
                      const float *__restrict__ spos, const float *__restrict__ grid,
                      const int Cr, const int plane0, float *__restrict__ yr, const int seg_slabs, const int nsegm,
-                     const int4 *__restrict__ work, const int4 *__restrict__ sorted, int *__restrict__ status)
+                     const int4 *__restrict__ work, const int4 *__restrict__ sorted, const WorkTickets tickets, int *__restrict__ status)
 {
     constexpr int m = W / 2 - 1;
     constexpr int TC = 17 - W;                                   // slabs per chunk
@@ -105,10 +106,11 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
     const int listed = work[0].z;
     if (OVERFLOW ? !listed : listed) return;
     const int n_items = OVERFLOW ? work[0].x : 1;
-    for (int item = OVERFLOW ? (int)blockIdx.x : 0; item < n_items; item += OVERFLOW ? (int)gridDim.x : 1) {
+    for (int item = OVERFLOW ? next_work_item(tickets, &L.ticket, -1, plane_local) : 0; item < n_items;
+         item = OVERFLOW ? next_work_item(tickets, &L.ticket, item, plane_local) : 1) {
     int pencil, sb, se;
     if constexpr (OVERFLOW) {
-        const int4 it = listed_item(sorted, item, n_items);
+        const int4 it = tickets.ring ? sorted[item] : listed_item(sorted, item, n_items);
         if (it.x / pencils != b) continue;  // another point set's piece
         pencil = it.x % pencils;
         sb = it.y;
@@ -528,11 +530,13 @@ static int launch_is_t(const Geom &g, const PlanLayout &L, const void *plan, con
         attr_done.mark();
     }
     hipLaunchKernelGGL((interp_stream_kernel<W, false, NG>), blocks, dim3(kIsThreads), sizeof(StreamLds), stream, g, to, gs,
-                       spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, work, sorted, status);
-    // the persistent launch over the work list (unbalanced plans; its workgroups leave at once otherwise)
+                       spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, work, sorted, WorkTickets{nullptr, 0u}, status);
+    // the persistent launch over the work list (unbalanced plans; its workgroups leave at once otherwise); entries are
+    // handed out by tickets when the launch's planes fit its share of the ticket ring, else round robin
+    const WorkTickets tickets{nplanes <= kTicketPlanes ? device_ticket_ring() : nullptr, next_launch_number()};
     const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
     hipLaunchKernelGGL((interp_stream_kernel<W, true, NG>), oblocks, dim3(kIsThreads), sizeof(StreamLds), stream, g, to,
-                       gs, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, work, sorted, status);
+                       gs, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, work, sorted, tickets, status);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }

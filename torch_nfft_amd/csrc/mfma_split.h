@@ -17,28 +17,36 @@ typedef float f32x4_dw __attribute__((ext_vector_type(4), aligned(4)));
 // value, are then normal f16 numbers instead of subnormals; the consumer multiplies by 2^-11 per operand.
 constexpr float kOpScale = 2048.0f;
 
-// Two-way f16 split of fp32 values in three VALU instructions per pair: hi = RN16(RN32(v)), lo = RN16(v - hi) with
-// the subtraction done by the mixed-precision FMA against the hi that is actually used (letting the compiler fuse
-// the residual under -ffp-contract=fast pairs it with a differently rounded hi: one f16 ulp off near ties).
+// Two-way f16 split of a pair of fp32 values: hi = RN16(v), lo = RN16(v - hi) with the residual formed in fp32 by the
+// mixed-precision FMA against the hi that is actually used (letting the compiler fuse the residual under
+// -ffp-contract=fast pairs it with a differently rounded hi: one f16 ulp off near ties).
+// Instruction choice (scripts/ubench/valu_rates.hip, cycles per wave instruction and SIMD with 4 waves resident):
+// v_fma_mixlo/mixhi_f16 -- an FMA with an f16 HALF-register result -- cost 8.5-8.9 (13 with one wave: the partial
+// register write chains them), v_fma_mix_f32 4.6, v_cvt_pk_f16_f32 4.5, v_pk_mul_f32 4.7, v_mul_f32 3.1.  So the f16
+// results are formed by the packed convert and only full-register FMAs are used: 4 instructions (18 cycles) instead of
+// 3 (21.5), and for products 5 (23) instead of 4 (35) -- the products are 10 x 16 instructions per K-block of the
+// spreading kernel.  Separate asm statements: the compiler interleaves the chains of neighbouring pairs.
 __device__ __forceinline__ void split_pair(const float v0, const float v1, unsigned &hi, unsigned &lo)
 {
-    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
-        "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(hi), "=&v"(lo)
-        : "v"(v0), "v"(v1));
+    float r0, r1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(v0), "v"(hi));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(v1), "v"(hi));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(r0), "v"(r1));
 }
 
-// The same for products p * a: hi = RN16(p a), lo = RN16(p a - hi), both from the exact product (4 instructions).
+// The same for products p * a: hi = RN16(RN32(p a)), lo = RN16(p a - hi) with the residual taken from the EXACT product
+// (one FMA), so hi + lo carries p a to ~2^-22 whichever way hi was rounded.
 __device__ __forceinline__ void split_product_pair(const float p0, const float a0, const float p1, const float a1,
                                                    unsigned &hi, unsigned &lo)
 {
-    asm("v_fma_mixlo_f16 %0, %2, %3, 0\n\t"
-        "v_fma_mixhi_f16 %0, %4, %5, 0\n\t"
-        "v_fma_mixlo_f16 %1, %2, %3, -%0 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %1, %4, %5, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(hi), "=&v"(lo)
-        : "v"(p0), "v"(a0), "v"(p1), "v"(a1));
+    float v0, v1, r0, r1;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(v0) : "v"(p0), "v"(a0));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(v1) : "v"(p1), "v"(a1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(p0), "v"(a0), "v"(hi));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(p1), "v"(a1), "v"(hi));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(r0), "v"(r1));
 }
 
 // One dword per active lane, global -> LDS without a register in between (LDS-DMA): lane l of the wave lands at

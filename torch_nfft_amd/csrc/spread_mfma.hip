@@ -100,6 +100,7 @@ struct __align__(16) MfmaLds {
     signed char raw_have[kRecRing][kSlots];
     int raw_slab[kRecRing][kNKB];
     int task_counter[2];
+    int ticket;                           // work-list entry of the workgroup (persistent launch: next_work_item)
     float inv_xscale;                     // (read by the staging threads once per step: a register would be spilled to scratch)
     int2 sched[kMaxSweep + 8];            // per slab: {K-blocks before it, point offset}; padded with the totals
     int sched_end[kMaxSweep + 8];         // per slab: end of its point range
@@ -112,7 +113,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                    const float *__restrict__ xr, const float *__restrict__ xs, const int64_t xs_stride,
                    const unsigned *__restrict__ xmax, const int Cr,
                    const int plane0, float *__restrict__ grid, const int seg_slabs, const int nsegm,
-                   const int4 *__restrict__ work, const int4 *__restrict__ sorted, int *__restrict__ status)
+                   const int4 *__restrict__ work, const int4 *__restrict__ sorted, const WorkTickets tickets, int *__restrict__ status)
 {
     constexpr int m = W / 2 - 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -137,11 +138,12 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     const int listed = work[0].z;
     if (OVERFLOW ? !listed : listed) return;
     const int n_items = OVERFLOW ? work[0].x : 1;
-    for (int item = OVERFLOW ? (int)blockIdx.x : 0; item < n_items; item += OVERFLOW ? (int)gridDim.x : 1) {
+    for (int item = OVERFLOW ? next_work_item(tickets, &L.ticket, -1, plane_local) : 0; item < n_items;
+         item = OVERFLOW ? next_work_item(tickets, &L.ticket, item, plane_local) : 1) {
     if (OVERFLOW && item != (int)blockIdx.x) __syncthreads();  // the previous item is done with the LDS
     int pencil, sb, se;
     if constexpr (OVERFLOW) {
-        const int4 it = listed_item(sorted, item, n_items);
+        const int4 it = tickets.ring ? sorted[item] : listed_item(sorted, item, n_items);
         if (it.x / pencils != b) continue;  // another point set's piece
         pencil = it.x % pencils;
         sb = it.y;
@@ -709,11 +711,13 @@ static int launch_mfma_t(const Geom &g, const PlanLayout &L, const void *plan, c
     const int4 *work = (const int4 *)(base + L.off_work), *sorted = work + 1 + L.work_cap;
     int *const status = device_status_block();
     hipLaunchKernelGGL((spread_mfma_kernel<W, false, OWNED>), blocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to,
-                       spos, xr, xs, L.cap, xmax, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, work, sorted, status);
-    // the persistent launch over the work list (unbalanced plans; its workgroups leave at once otherwise)
+                       spos, xr, xs, L.cap, xmax, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, work, sorted, WorkTickets{nullptr, 0u}, status);
+    // the persistent launch over the work list (unbalanced plans; its workgroups leave at once otherwise); entries are
+    // handed out by tickets when the launch's planes fit its share of the ticket ring, else round robin
+    const WorkTickets tickets{nplanes <= kTicketPlanes ? device_ticket_ring() : nullptr, next_launch_number()};
     const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
     hipLaunchKernelGGL((spread_mfma_kernel<W, true, OWNED>), oblocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to,
-                       spos, xr, xs, L.cap, xmax, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, work, sorted, status);
+                       spos, xr, xs, L.cap, xmax, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, work, sorted, tickets, status);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }
