@@ -54,7 +54,8 @@ PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)
     // work list of the matrix-core kernels (wide tiling; segment_split_kernel / work_order_kernel below): a header,
     // the list and its copy in launch order.  ranges + entries / 2048 bounds the list (pieces hold >= 2048 points)
     L.work_cap = g.wide ? (int64_t)g.nta[1] * g.nta[2] * B * kSegMax + L.cap / 2048 + 16 : 0;
-    L.off_work = o;    o = align_up(o + (g.wide ? (1 + 2 * L.work_cap) * 16 : 0), 256);
+    L.work_head = 1 + (B * 8 + 15) / 16;
+    L.off_work = o;    o = align_up(o + (g.wide ? (L.work_head + 2 * L.work_cap) * 16 : 0), 256);
     // the count passes leave the keys they computed for the scatter passes (two bytes per point / record instead of
     // two or three more split_cell + tile-index evaluations)
     L.off_key1 = o;    o = align_up(o + (L.two_level && !g.owned ? n * 2 : 0), 256);
@@ -414,8 +415,8 @@ sort2_scatter_kernel(Geom g, int npencils, int nblocks, const int *__restrict__ 
 // into pieces of about `target` points.  One wave per (point set, pencil), lane r = range r of the pencil.
 // work[0] = {entries, 1 if any range was cut, 0, 0}; entries {point set * pencils + pencil, first slab, end slab, points}.
 __global__ void __launch_bounds__(64)
-segment_split_kernel(Geom g, int npl /* point sets x pencils */, int runs, int target, const int *__restrict__ offsets,
-                     int4 *__restrict__ work, int capacity)
+segment_split_kernel(Geom g, int npl /* point sets x pencils */, int pencils, int runs, int target,
+                     const int *__restrict__ offsets, int4 *__restrict__ work, int4 *__restrict__ list, int capacity)
 {
     const int pl = blockIdx.x;
     if (pl >= npl) return;
@@ -447,57 +448,74 @@ segment_split_kernel(Geom g, int npl /* point sets x pencils */, int runs, int t
         // item the chunks of slabs that START in it -- such a chunk may reach into the next item's slabs)
         if (end > prev) {
             const int slot = atomicAdd(&((int *)work)[0], 1);
-            if (slot < capacity) work[1 + slot] = make_int4(pl, prev, end, piece_pts);
+            if (slot < capacity) {
+                list[slot] = make_int4(pl, prev, end, piece_pts);
+                atomicAdd(&((int2 *)(work + 1))[pl / pencils].x, 1);
+            }
         }
         prev = end;
     }
 }
 
-// Decides how the matrix-core kernels walk the work of this plan and, when it is the list, puts it in launch order.
-//   balanced input (no range was cut and the largest range holds < 1.5 x the mean over ALL ranges, empty ones included:
-//   every uniform input): work[0].z = 0 -- one workgroup per range in grid order, straight-line code (neighbouring
-//   ranges run side by side; measured 1 % faster at config C3 than any sorted order);
-//   otherwise work[0].z = 1 -- ONE persistent launch walks `sorted`, the list biggest first (a counting sort into 16
-//   size classes, sixteenths of the largest entry), so that the tail of the launch is made of small items.  Clustered
-//   inputs leave most CUs idle behind their few heavy ranges in grid order (43 % CU utilisation at C3-clustered), and a
-//   separate launch for the cut-off pieces (rounds 2-3) started only when the last first piece was done.
-// One workgroup.
+// Decides how the matrix-core kernels walk the work of this plan and puts the list in launch order.  One workgroup per
+// point set b: its entries are copied to sorted[start_b ...), biggest first (a counting sort into 16 size classes,
+// sixteenths of the set's largest entry), and set_hdr[b] = {entries, start_b}.
+//   balanced plan (no range was cut and in no set the largest range holds >= 1.5 x the mean over ALL its ranges, empty ones
+//   included: every uniform input): work[0].z stays 0 -- one workgroup per range in grid order, straight-line code
+//   (neighbouring ranges run side by side; measured 1 % faster at config C3 than any sorted order);
+//   otherwise work[0].z = 1 -- ONE persistent launch per plane walks the set's part of `sorted`, so that the tail of the
+//   launch is made of small items.  Clustered inputs leave most CUs idle behind their few heavy ranges in grid order (43 %
+//   CU utilisation at C3-clustered), and a separate launch for the cut-off pieces (rounds 2-3) started only when the
+//   last first piece was done.
 constexpr int kOrderClasses = 16;
 __global__ void __launch_bounds__(1024)
-work_order_kernel(int4 *__restrict__ work, int4 *__restrict__ sorted, int capacity, int nranges, int forced)
+work_order_kernel(int4 *__restrict__ work, const int4 *__restrict__ list, int4 *__restrict__ sorted, int capacity,
+                  int pencils, int ranges_per_set, int forced)
 {
     __shared__ int cnt[kOrderClasses][1024];  // [class][thread]: entries of the class in the thread's chunk -> their first slot
     __shared__ int total[kOrderClasses];
-    __shared__ int maxpts;
+    __shared__ int maxpts, start;
     __shared__ unsigned long long sumpts;
+    const int b = blockIdx.x;
     const int4 hdr = work[0];
     const int nitems = min(hdr.x, capacity);
-    const int4 *list = work + 1;
-    if (threadIdx.x == 0) { maxpts = 1; sumpts = 0ull; }
+    int2 *const set_hdr = (int2 *)(work + 1);
+    if (threadIdx.x == 0) { maxpts = 1; sumpts = 0ull; start = 0; }
     __syncthreads();
-    // thread t owns the contiguous chunk [t per, (t + 1) per) of the list
+    {   // entries of the sets in front of this one
+        int before = 0;
+        for (int q = threadIdx.x; q < b; q += 1024) before += set_hdr[q].x;
+        if (before) atomicAdd(&start, before);
+    }
+    // thread t owns the contiguous chunk [t per, (t + 1) per) of the list; only this set's entries count
     const int per = (nitems + 1023) / 1024;
     const int lo = min(nitems, (int)threadIdx.x * per), hi = min(nitems, lo + per);
+    const int pl0 = b * pencils, pl1 = pl0 + pencils;
     int mx = 0;
     unsigned long long sm = 0ull;
     for (int it = lo; it < hi; ++it) {
-        const int pts = list[it].w;
-        mx = max(mx, pts);
-        sm += (unsigned long long)pts;
+        const int4 e = list[it];
+        if (e.x < pl0 || e.x >= pl1) continue;
+        mx = max(mx, e.w);
+        sm += (unsigned long long)e.w;
     }
     atomicMax(&maxpts, mx);
     if (sm) atomicAdd(&sumpts, sm);
     __syncthreads();
-    const bool listed = nitems > 0 && (forced || hdr.y != 0 || (double)maxpts * (double)nranges >= 1.5 * (double)sumpts);
-    if (threadIdx.x == 0) ((int *)work)[2] = listed ? 1 : 0;
-    if (!listed) return;
+    if (threadIdx.x == 0) {
+        set_hdr[b].y = start;
+        if (forced || hdr.y != 0 || (sumpts > 0 && (double)maxpts * (double)ranges_per_set >= 1.5 * (double)sumpts))
+            atomicOr(&((int *)work)[2], 1);
+    }
     const float scale = (float)kOrderClasses / (float)maxpts;
     auto size_class = [&](const int pts) { return kOrderClasses - 1 - min(kOrderClasses - 1, (int)((float)pts * scale)); };  // 0 = biggest
     int mine[kOrderClasses];
 #pragma unroll
     for (int c = 0; c < kOrderClasses; ++c) mine[c] = 0;
     for (int it = lo; it < hi; ++it) {
-        const int c = size_class(list[it].w);
+        const int4 e = list[it];
+        if (e.x < pl0 || e.x >= pl1) continue;
+        const int c = size_class(e.w);
 #pragma unroll
         for (int q = 0; q < kOrderClasses; ++q) mine[q] += q == c ? 1 : 0;
     }
@@ -523,7 +541,7 @@ work_order_kernel(int4 *__restrict__ work, int4 *__restrict__ sorted, int capaci
     __syncthreads();
     int slot[kOrderClasses];
     {
-        int before = 0;
+        int before = start;
 #pragma unroll
         for (int c = 0; c < kOrderClasses; ++c) {
             slot[c] = before + cnt[c][threadIdx.x];
@@ -532,6 +550,7 @@ work_order_kernel(int4 *__restrict__ work, int4 *__restrict__ sorted, int capaci
     }
     for (int it = lo; it < hi; ++it) {
         const int4 e = list[it];
+        if (e.x < pl0 || e.x >= pl1) continue;
         const int c = size_class(e.w);
         int s_ = 0;
 #pragma unroll
@@ -596,12 +615,13 @@ static int launch_segment_split(const Geom &g, const PlanLayout &L, int64_t n, i
     const int ncu = device_cu_count();
     const int runs = seg_base_runs(n, B, pencils, g.M, ncu);
     const int target = (int)std::min<int64_t>(seg_target_points(n, B, ncu), int64_t(1) << 30);
-    NFFT_HIP_CHECK(hipMemsetAsync(work, 0, 16, stream));
+    NFFT_HIP_CHECK(hipMemsetAsync(work, 0, (size_t)L.work_head * 16, stream));
     if (npl <= 0) return 0;
-    hipLaunchKernelGGL(segment_split_kernel, dim3((unsigned)npl), dim3(64), 0, stream, g, (int)npl, runs, target, offsets,
-                       work, (int)L.work_cap);
-    hipLaunchKernelGGL(work_order_kernel, dim3(1), dim3(1024), 0, stream, work, work + 1 + L.work_cap, (int)L.work_cap,
-                       (int)(npl * runs), work_list_forced() ? 1 : 0);
+    int4 *const list = work + L.work_head;
+    hipLaunchKernelGGL(segment_split_kernel, dim3((unsigned)npl), dim3(64), 0, stream, g, (int)npl, (int)pencils, runs, target,
+                       offsets, work, list, (int)L.work_cap);
+    hipLaunchKernelGGL(work_order_kernel, dim3((unsigned)B), dim3(1024), 0, stream, work, list, list + L.work_cap,
+                       (int)L.work_cap, (int)pencils, (int)(pencils * runs), work_list_forced() ? 1 : 0);
     return 0;
 }
 

@@ -375,9 +375,12 @@ __device__ __forceinline__ int4 listed_item(const int4 *__restrict__ sorted, con
 // Wide tiling, load balance of the matrix-core kernels: a pencil is swept in `runs` equal ranges of slabs (as many as
 // give ~5.4 workgroups per CU for an average pencil).  Balanced inputs (every uniform one) run one workgroup per range.
 // Ranges that hold far more points than average (clustered inputs) are cut further by point count at plan time, and all
-// pieces go to a work list in the plan ([0] = {entries, any range cut, 1 = walk the list, 0}, then {point set
-// * pencils + pencil, first slab, end slab, points}, then the same entries biggest first) that ONE persistent launch
-// walks instead.  Both launches are always enqueued; the one that is not the plan's returns at once.
+// pieces go to a work list in the plan:
+//   [0] = {entries, any range cut, 1 = walk the list, 0};  then one int2 {entries, first entry} per point set;
+//   then the entries {point set * pencils + pencil, first slab, end slab, points} as they were produced;
+//   then the same entries grouped by point set, every set's biggest first.
+// ONE persistent launch walks a set's part of the sorted list instead (entries handed out by tickets, below).  Both
+// launches are always enqueued; the one that is not the plan's returns at once.
 constexpr int kSegMax = 32;      // most ranges per pencil
 constexpr int kSegPieces = 16;   // most pieces a range is cut into
 inline int64_t seg_target_points(int64_t n, int64_t nsets, int ncu)
@@ -418,7 +421,8 @@ struct PlanLayout {
     int64_t off_offsets, off_cursor, off_perm, off_spos, off_scan, scan_bytes;
     int64_t off_hist, off_hscan, off_tmp, off_hist2;
     int64_t off_groups;  // column-group starts (two ints per plan bin) when `grouped`
-    int64_t off_work, work_cap;  // wide tiling: work list {header, work_cap entries, work_cap entries in launch order} (binning.hip)
+    int64_t off_work, work_cap, work_head;  // wide tiling: work list {work_head 16-byte words: header + one int2 per point
+                                            // set, work_cap entries, work_cap entries in launch order} (binning.hip)
     int64_t off_key1, off_key2;  // sort scratch: first-level bin of every point, fine key of every record (16 bits each)
     bool grouped;        // the plan is ordered by column group inside the slabs (Geom::CG == 3, two-level sort)
     int64_t total;

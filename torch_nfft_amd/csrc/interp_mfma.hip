@@ -64,15 +64,17 @@ interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets,
     // (work items as in spread_mfma.hip: one workgroup per range, or a persistent grid over the plan's work list)
     const int listed = work[0].z;
     if (OVERFLOW ? !listed : listed) return;
-    const int n_items = OVERFLOW ? work[0].x : 1;
+    // (a plane walks its own point set's part of the sorted list: set_hdr[b] = {entries, first entry})
+    const int2 set_hdr = OVERFLOW ? ((const int2 *)(work + 1))[b] : make_int2(1, 0);
+    const int n_items = set_hdr.x;
+    const int4 *const entries = sorted + set_hdr.y;
     for (int item = OVERFLOW ? next_work_item(tickets, &L.ticket, -1, plane_local) : 0; item < n_items;
          item = OVERFLOW ? next_work_item(tickets, &L.ticket, item, plane_local) : 1) {
     if (OVERFLOW && item != (int)blockIdx.x) __syncthreads();  // the previous item is done with the LDS
     int pencil, sb, se;
     if constexpr (OVERFLOW) {
-        const int4 it = tickets.ring ? sorted[item] : listed_item(sorted, item, n_items);
-        if (it.x / pencils != b) continue;  // another point set's piece
-        pencil = it.x % pencils;
+        const int4 it = tickets.ring ? entries[item] : listed_item(entries, item, n_items);
+        pencil = it.x - b * pencils;
         sb = it.y;
         se = it.z;
     } else {
@@ -286,7 +288,7 @@ static int launch_gm_t(const Geom &g, const PlanLayout &L, const void *plan, con
         attr_done.mark();
     }
     const char *base = (const char *)plan;
-    const int4 *work = (const int4 *)(base + L.off_work), *sorted = work + 1 + L.work_cap;
+    const int4 *work = (const int4 *)(base + L.off_work), *sorted = work + L.work_head + L.work_cap;
     hipLaunchKernelGGL((interp_mfma_kernel<W, false>), blocks, dim3(kGmThreads), sizeof(GatherMfmaLds), stream, g, to,
                        spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, work, sorted, WorkTickets{nullptr, 0u});
     // the persistent launch over the work list (unbalanced plans; its workgroups leave at once otherwise); entries are

@@ -105,14 +105,16 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
     // (work items as in spread_mfma.hip: one workgroup per range, or a persistent grid over the plan's work list)
     const int listed = work[0].z;
     if (OVERFLOW ? !listed : listed) return;
-    const int n_items = OVERFLOW ? work[0].x : 1;
+    // (a plane walks its own point set's part of the sorted list: set_hdr[b] = {entries, first entry})
+    const int2 set_hdr = OVERFLOW ? ((const int2 *)(work + 1))[b] : make_int2(1, 0);
+    const int n_items = set_hdr.x;
+    const int4 *const entries = sorted + set_hdr.y;
     for (int item = OVERFLOW ? next_work_item(tickets, &L.ticket, -1, plane_local) : 0; item < n_items;
          item = OVERFLOW ? next_work_item(tickets, &L.ticket, item, plane_local) : 1) {
     int pencil, sb, se;
     if constexpr (OVERFLOW) {
-        const int4 it = tickets.ring ? sorted[item] : listed_item(sorted, item, n_items);
-        if (it.x / pencils != b) continue;  // another point set's piece
-        pencil = it.x % pencils;
+        const int4 it = tickets.ring ? entries[item] : listed_item(entries, item, n_items);
+        pencil = it.x - b * pencils;
         sb = it.y;
         se = it.z;
     } else {
@@ -513,7 +515,7 @@ static int launch_is_t(const Geom &g, const PlanLayout &L, const void *plan, con
     const int *to = (const int *)(base + L.off_offsets);
     const int *gs = (const int *)(base + L.off_groups);
     const float *spos = (const float *)(base + L.off_spos);
-    const int4 *work = (const int4 *)(base + L.off_work), *sorted = work + 1 + L.work_cap;
+    const int4 *work = (const int4 *)(base + L.off_work), *sorted = work + L.work_head + L.work_cap;
     const int64_t pencils = (int64_t)g.nta[1] * g.nta[2];
     int64_t nsets = g.tiles_per_batch > 0 ? L.ntiles / g.tiles_per_batch : 1;
     if (nsets < 1) nsets = 1;

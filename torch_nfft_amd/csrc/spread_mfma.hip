@@ -137,15 +137,17 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     // are enqueued; the one that is not the plan's leaves here.  (two instantiations: the item loop costs registers)
     const int listed = work[0].z;
     if (OVERFLOW ? !listed : listed) return;
-    const int n_items = OVERFLOW ? work[0].x : 1;
+    // (a plane walks its own point set's part of the sorted list: set_hdr[b] = {entries, first entry})
+    const int2 set_hdr = OVERFLOW ? ((const int2 *)(work + 1))[b] : make_int2(1, 0);
+    const int n_items = set_hdr.x;
+    const int4 *const entries = sorted + set_hdr.y;
     for (int item = OVERFLOW ? next_work_item(tickets, &L.ticket, -1, plane_local) : 0; item < n_items;
          item = OVERFLOW ? next_work_item(tickets, &L.ticket, item, plane_local) : 1) {
     if (OVERFLOW && item != (int)blockIdx.x) __syncthreads();  // the previous item is done with the LDS
     int pencil, sb, se;
     if constexpr (OVERFLOW) {
-        const int4 it = tickets.ring ? sorted[item] : listed_item(sorted, item, n_items);
-        if (it.x / pencils != b) continue;  // another point set's piece
-        pencil = it.x % pencils;
+        const int4 it = tickets.ring ? entries[item] : listed_item(entries, item, n_items);
+        pencil = it.x - b * pencils;
         sb = it.y;
         se = it.z;
     } else {
@@ -708,7 +710,7 @@ static int launch_mfma_t(const Geom &g, const PlanLayout &L, const void *plan, c
         attr_done.mark();
     }
     const char *base = (const char *)plan;
-    const int4 *work = (const int4 *)(base + L.off_work), *sorted = work + 1 + L.work_cap;
+    const int4 *work = (const int4 *)(base + L.off_work), *sorted = work + L.work_head + L.work_cap;
     int *const status = device_status_block();
     hipLaunchKernelGGL((spread_mfma_kernel<W, false, OWNED>), blocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to,
                        spos, xr, xs, L.cap, xmax, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, work, sorted, WorkTickets{nullptr, 0u}, status);
