@@ -430,7 +430,14 @@ segment_split_kernel(Geom g, int npl /* point sets x pencils */, int pencils, in
     int pieces = (int)(((int64_t)pts + target / 2) / target);
     pieces = pieces < 1 ? 1 : (pieces > kSegPieces ? kSegPieces : pieces);
     // (pieces <= 1 + pts / target with target >= 2048: the list's capacity, ranges + entries / 2048, always suffices)
-    if (pieces > 1) atomicOr(&((int *)work)[1], 1);
+    // the plan runs from its list (work[0].z) when a range is cut or holds >= 1.5 x the mean over ALL ranges of its point
+    // set, empty ones included (work_order_kernel)
+    {
+        const int64_t first = (int64_t)(pl / pencils) * pencils * g.np0;
+        const int64_t set_pts = offsets[first + (int64_t)pencils * g.np0] - offsets[first];
+        if (pieces > 1 || (pts > 0 && (double)pts * (double)(pencils * runs) >= 1.5 * (double)set_pts))
+            atomicOr(&((int *)work)[2], 1);
+    }
     int prev = sb;  // end of the previous piece
     for (int p = 1; p <= pieces; ++p) {
         int end = se;
@@ -457,30 +464,29 @@ segment_split_kernel(Geom g, int npl /* point sets x pencils */, int pencils, in
     }
 }
 
-// Decides how the matrix-core kernels walk the work of this plan and puts the list in launch order.  One workgroup per
-// point set b: its entries are copied to sorted[start_b ...), biggest first (a counting sort into 16 size classes,
-// sixteenths of the set's largest entry), and set_hdr[b] = {entries, start_b}.
-//   balanced plan (no range was cut and in no set the largest range holds >= 1.5 x the mean over ALL its ranges, empty ones
-//   included: every uniform input): work[0].z stays 0 -- one workgroup per range in grid order, straight-line code
-//   (neighbouring ranges run side by side; measured 1 % faster at config C3 than any sorted order);
-//   otherwise work[0].z = 1 -- ONE persistent launch per plane walks the set's part of `sorted`, so that the tail of the
-//   launch is made of small items.  Clustered inputs leave most CUs idle behind their few heavy ranges in grid order (43 %
-//   CU utilisation at C3-clustered), and a separate launch for the cut-off pieces (rounds 2-3) started only when the
-//   last first piece was done.
+// Puts the work list of an unbalanced plan in launch order (a balanced one -- segment_split_kernel saw no range that was
+// cut or holds >= 1.5 x its set's mean: every uniform input -- returns at once: its kernels run one workgroup per range in
+// grid order, straight-line code, neighbouring ranges side by side; measured 1 % faster at config C3 than any sorted
+// order).  One workgroup per point set b: its entries are copied to sorted[start_b ...), biggest first (a counting sort
+// into 16 size classes, sixteenths of the set's largest entry), and set_hdr[b] = {entries, start_b}.  ONE persistent
+// launch per plane then walks the set's part of `sorted`, so that the tail of the launch is made of small items:
+// clustered inputs leave most CUs idle behind their few heavy ranges in grid order (43 % CU utilisation at C3-clustered),
+// and a separate launch for the cut-off pieces (rounds 2-3) started only when the last first piece was done.
 constexpr int kOrderClasses = 16;
 __global__ void __launch_bounds__(1024)
 work_order_kernel(int4 *__restrict__ work, const int4 *__restrict__ list, int4 *__restrict__ sorted, int capacity,
-                  int pencils, int ranges_per_set, int forced)
+                  int pencils, int forced)
 {
     __shared__ int cnt[kOrderClasses][1024];  // [class][thread]: entries of the class in the thread's chunk -> their first slot
     __shared__ int total[kOrderClasses];
     __shared__ int maxpts, start;
-    __shared__ unsigned long long sumpts;
     const int b = blockIdx.x;
     const int4 hdr = work[0];
+    if (!hdr.z && !forced) return;  // balanced: nobody reads the list
+    if (forced && b == 0 && threadIdx.x == 0) ((int *)work)[2] = 1;
     const int nitems = min(hdr.x, capacity);
     int2 *const set_hdr = (int2 *)(work + 1);
-    if (threadIdx.x == 0) { maxpts = 1; sumpts = 0ull; start = 0; }
+    if (threadIdx.x == 0) { maxpts = 1; start = 0; }
     __syncthreads();
     {   // entries of the sets in front of this one
         int before = 0;
@@ -492,21 +498,13 @@ work_order_kernel(int4 *__restrict__ work, const int4 *__restrict__ list, int4 *
     const int lo = min(nitems, (int)threadIdx.x * per), hi = min(nitems, lo + per);
     const int pl0 = b * pencils, pl1 = pl0 + pencils;
     int mx = 0;
-    unsigned long long sm = 0ull;
     for (int it = lo; it < hi; ++it) {
         const int4 e = list[it];
-        if (e.x < pl0 || e.x >= pl1) continue;
-        mx = max(mx, e.w);
-        sm += (unsigned long long)e.w;
+        if (e.x >= pl0 && e.x < pl1) mx = max(mx, e.w);
     }
     atomicMax(&maxpts, mx);
-    if (sm) atomicAdd(&sumpts, sm);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        set_hdr[b].y = start;
-        if (forced || hdr.y != 0 || (sumpts > 0 && (double)maxpts * (double)ranges_per_set >= 1.5 * (double)sumpts))
-            atomicOr(&((int *)work)[2], 1);
-    }
+    if (threadIdx.x == 0) set_hdr[b].y = start;
     const float scale = (float)kOrderClasses / (float)maxpts;
     auto size_class = [&](const int pts) { return kOrderClasses - 1 - min(kOrderClasses - 1, (int)((float)pts * scale)); };  // 0 = biggest
     int mine[kOrderClasses];
@@ -621,7 +619,7 @@ static int launch_segment_split(const Geom &g, const PlanLayout &L, int64_t n, i
     hipLaunchKernelGGL(segment_split_kernel, dim3((unsigned)npl), dim3(64), 0, stream, g, (int)npl, (int)pencils, runs, target,
                        offsets, work, list, (int)L.work_cap);
     hipLaunchKernelGGL(work_order_kernel, dim3((unsigned)B), dim3(1024), 0, stream, work, list, list + L.work_cap,
-                       (int)L.work_cap, (int)pencils, (int)(pencils * runs), work_list_forced() ? 1 : 0);
+                       (int)L.work_cap, (int)pencils, work_list_forced() ? 1 : 0);
     return 0;
 }
 
