@@ -37,6 +37,7 @@ struct ColGeom {
                         // 129 complex numbers put every run across two lines: the passes fetched ~2x their input)
     int NB;             // band+ rows: N + 1
     int NC, logNC;      // columns per tile
+    int TG;             // tiles that share a 128-byte line (16 / NC; 1: the XCD-aware tile mapping below is off)
     float param;        // pi/3 * m / N^2  (phi_hat_inv exponent scale)
 };
 
@@ -45,6 +46,30 @@ __device__ __forceinline__ float phi_hat_inv_f(int k, float param) { return expf
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// Column passes, workgroup -> (column tile, row, plane).  A tile of NC < 16 columns is an NC * 8-byte run of every row: TG =
+// 16 / NC neighbouring tiles share each 128-byte line, and consecutive workgroup ids go to different XCDs (round robin),
+// each with its own L2 -- so every line was fetched from HBM once per tile (FETCH_SIZE 2.05x the input at C3).  Here the
+// TG tiles of a line get ids that are 8 apart: same XCD, dispatched together, ONE fetch.  Ids are permuted inside blocks
+// of 8 * TG consecutive ones (the launch rounds the tile count up to a multiple of TG; the spare tiles return at once).
+__device__ __forceinline__ void column_tile_of_block(const int tg, int &tile, int &row, int64_t &plane)
+{
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    unsigned long long id = blockIdx.x + (unsigned long long)gx * (blockIdx.y + (unsigned long long)gy * blockIdx.z);
+    if (tg > 1) {
+        const unsigned long long total = (unsigned long long)gx * gy * gridDim.z;
+        const unsigned span = 8u * (unsigned)tg;
+        const unsigned long long base = id - id % span;
+        if (base + span <= total) {
+            const unsigned r = (unsigned)(id - base);
+            id = base + (unsigned long long)(r & 7u) * (unsigned)tg + (r >> 3);
+        }
+    }
+    tile = (int)(id % gx);
+    const unsigned long long q = id / gx;
+    row = (int)(q % gy);
+    plane = (int64_t)(q / gy);
 }
 
 // tw[j] = exp(-2 pi i j / M), j < M/2: compile-time tables in the code object (one per grid size the passes support), so
@@ -288,9 +313,11 @@ adj_axis1_kernel(ColGeom cg_in, const float2 *__restrict__ tw, const float2 *__r
     float2 *ltw = smem;
     float2 *buf = smem + cg.M / 2;
     const int tid = threadIdx.x;
-    const int c0 = blockIdx.x << cg.logNC;
-    const int u0 = blockIdx.y;
-    const int64_t plane = blockIdx.z;
+    int tile_x, u0;
+    int64_t plane;
+    column_tile_of_block(cg.TG, tile_x, u0, plane);
+    const int c0 = tile_x << cg.logNC;
+    if (c0 >= cg.KC) return;  // (a spare tile of the rounded-up launch)
     stage_twiddles(ltw, tw, cg.M, tid);
     const float2 *src = S + ((plane * cg.M + u0) * cg.M) * cg.SR;
     batched_fill<16>(cg.M << cg.logNC, tid,
@@ -347,9 +374,11 @@ adj_axis0_kernel(ColGeom cg_in, const float2 *__restrict__ tw, const float2 *__r
     float2 *buf = smem + cg.M / 2;
     float2 *buf2 = buf + (cg.M << cg.logNC);
     const int tid = threadIdx.x;
-    const int c0 = blockIdx.x << cg.logNC;
-    const int j1 = blockIdx.y;
-    const int64_t col_local = blockIdx.z;  // (batch, column) pair inside this chunk of planes
+    int tile_x, j1;
+    int64_t col_local;  // (batch, column) pair inside this chunk of planes
+    column_tile_of_block(cg.TG, tile_x, j1, col_local);
+    const int c0 = tile_x << cg.logNC;
+    if (c0 >= cg.KC) return;  // (a spare tile of the rounded-up launch)
     stage_twiddles(ltw, tw, cg.M, tid);
     const int64_t plane = XCOMPLEX ? col_local * 2 : col_local;
     const int64_t pstride = (int64_t)cg.M * cg.NB * cg.KS;
@@ -433,9 +462,11 @@ fwd_axis0_kernel(ColGeom cg_in, const float2 *__restrict__ tw, const void *__res
     float2 *ltw = smem;
     float2 *buf = smem + cg.M / 2;
     const int tid = threadIdx.x;
-    const int c0 = blockIdx.x << cg.logNC;
-    const int j1 = blockIdx.y;
-    const int64_t pl = blockIdx.z;
+    int tile_x, j1;
+    int64_t pl;
+    column_tile_of_block(cg.TG, tile_x, j1, pl);
+    const int c0 = tile_x << cg.logNC;
+    if (c0 >= cg.KC) return;  // (a spare tile of the rounded-up launch)
     stage_twiddles(ltw, tw, cg.M, tid);
     for (int idx = tid; idx < (cg.M << cg.logNC); idx += kFftThreads) buf[idx] = make_float2(0.f, 0.f);
     __syncthreads();
@@ -487,9 +518,11 @@ fwd_axis1_kernel(ColGeom cg_in, const float2 *__restrict__ tw, const float2 *__r
     float2 *ltw = smem;
     float2 *buf = smem + cg.M / 2;
     const int tid = threadIdx.x;
-    const int c0 = blockIdx.x << cg.logNC;
-    const int u0 = blockIdx.y;
-    const int64_t plane = blockIdx.z;
+    int tile_x, u0;
+    int64_t plane;
+    column_tile_of_block(cg.TG, tile_x, u0, plane);
+    const int c0 = tile_x << cg.logNC;
+    if (c0 >= (cg.SR == cg.KS ? cg.KC : cg.Mh)) return;  // (a spare tile of the rounded-up launch)
     float2 *dst = S + ((plane * cg.M + u0) * cg.M) * cg.SR;
     const int width = cg.SR == cg.KS ? cg.KC : cg.Mh;  // columns of S that exist (the compact layout has no zero tail)
     if (c0 >= cg.KC) {  // zero tail of the padded half spectrum
@@ -1152,7 +1185,19 @@ ColGeom make_col_geom(const Geom &g, bool two_buffers, bool compact)
     cg.logNC = 0;
     while ((1 << cg.logNC) < nc) ++cg.logNC;
     cg.param = 1.047197551196597746f * (float)g.m / ((float)g.N * (float)g.N);
+    static const bool pairs_off = [] {
+        const char *env = std::getenv("NFFT_HIP_COL_XCD");
+        return env && env[0] == '0';
+    }();
+    cg.TG = pairs_off || nc >= 16 ? 1 : 16 / nc;
     return cg;
+}
+
+// column tiles of a launch: whole groups of TG (column_tile_of_block)
+static inline unsigned col_tiles(const ColGeom &cg, int columns = 0)
+{
+    const int t = ((columns > 0 ? columns : cg.KC) + cg.NC - 1) / cg.NC;
+    return (unsigned)((t + cg.TG - 1) / cg.TG * cg.TG);
 }
 
 size_t col_lds_bytes(const ColGeom &cg, bool two_buffers)
@@ -1208,7 +1253,7 @@ int launch_colfft_adjoint(const Geom &g, const float2 *spec, bool compact, void 
     if (!tw) { set_error("no twiddle table for this grid size"); return 4; }
     {
         const ColGeom cg = make_col_geom(g, false, compact);
-        const dim3 grid((cg.KC + cg.NC - 1) / cg.NC, g.M, (unsigned)nplanes);
+        const dim3 grid(col_tiles(cg), g.M, (unsigned)nplanes);
         const size_t lds = col_lds_bytes(cg, false);
         col_dispatch(cg, [&](auto lm, auto ln) {
             constexpr int LM = decltype(lm)::value, LN = decltype(ln)::value;
@@ -1221,7 +1266,7 @@ int launch_colfft_adjoint(const Geom &g, const float2 *spec, bool compact, void 
         const ColGeom cg = make_col_geom(g, two, compact);
         const int ppc = two ? 2 : 1;
         const int64_t col0 = plane0 / ppc, ncols = nplanes / ppc;
-        const dim3 grid((cg.KC + cg.NC - 1) / cg.NC, cg.NB, (unsigned)ncols);
+        const dim3 grid(col_tiles(cg), cg.NB, (unsigned)ncols);
         const size_t lds = col_lds_bytes(cg, two);
         col_dispatch(cg, [&](auto lm, auto ln) {
             constexpr int LM = decltype(lm)::value, LN = decltype(ln)::value;
@@ -1256,7 +1301,7 @@ int launch_colfft_forward(const Geom &g, const void *xhat, void *scratch, int64_
     col_dispatch(cg, [&](auto lm, auto ln) {
         constexpr int LM = decltype(lm)::value, LN = decltype(ln)::value;
         {
-            const dim3 grid((cg.KC + cg.NC - 1) / cg.NC, cg.NB, (unsigned)nplanes);
+            const dim3 grid(col_tiles(cg), cg.NB, (unsigned)nplanes);
             if (x_is_complex) {
                 allow_lds(fwd_axis0_kernel<LM, LN, true>, lds);
                 hipLaunchKernelGGL((fwd_axis0_kernel<LM, LN, true>), grid, dim3(kFftThreads), lds, stream, cg, tw, xhat, C, ppc, plane0, T);
@@ -1266,7 +1311,7 @@ int launch_colfft_forward(const Geom &g, const void *xhat, void *scratch, int64_
             }
         }
         {
-            const dim3 grid(((compact ? cg.KC : cg.Mh) + cg.NC - 1) / cg.NC, g.M, (unsigned)nplanes);
+            const dim3 grid(col_tiles(cg, compact ? cg.KC : cg.Mh), g.M, (unsigned)nplanes);
             allow_lds(fwd_axis1_kernel<LM, LN>, lds);
             hipLaunchKernelGGL((fwd_axis1_kernel<LM, LN>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, spec);
         }
