@@ -379,3 +379,35 @@ def test_grid_2d_16384_squared(tn):
     lhs = torch.sum(ya * xh.conj())
     rhs = torch.sum(x.to(torch.complex64) * yf.conj())
     assert abs(complex(lhs) - complex(rhs)) < 1e-4 * abs(complex(lhs)) + 1e-2
+
+
+def test_work_list_tickets_on_concurrent_streams(tn):
+    """Two streams run the persistent (work-list) kernels at the same time on the SAME cached plan: the ticket words that
+    hand out the list live in a ring owned by the library, one set per launch -- the plan itself is read-only -- so the
+    launches must not disturb each other.  4e6 clustered points (most work items are cut pieces), three rounds, results
+    compared with the same transforms run one after the other."""
+    N, m, n = 128, 4, 4_000_000
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    centres = torch.rand((4, 3), generator=gen, device="cuda") - 0.5
+    pos = centres[torch.randint(0, 4, (n,), generator=gen, device="cuda")] + 0.03 * torch.randn((n, 3), generator=gen, device="cuda")
+    pos = pos - torch.floor(pos + 0.5)
+    xa = torch.randn((n,), generator=gen, device="cuda")
+    xb = torch.randn((n,), generator=gen, device="cuda")
+    ya = tn.nfft_adjoint(xa, pos, None, bandwidth=N, cutoff=m)      # (also builds and caches the plan)
+    yb = tn.nfft_adjoint(xb, pos, None, bandwidth=N, cutoff=m)
+    fa = tn.nfft_forward(ya, pos, None, cutoff=m)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            ya2 = tn.nfft_adjoint(xa, pos, None, bandwidth=N, cutoff=m)
+            fa2 = tn.nfft_forward(ya, pos, None, cutoff=m)
+        with torch.cuda.stream(s2):
+            yb2 = tn.nfft_adjoint(xb, pos, None, bandwidth=N, cutoff=m)
+        torch.cuda.synchronize()
+        # (the scatter variant's float atomics are not bitwise reproducible: compare at the parity tolerance)
+        assert rel_l2(ya2.cpu().numpy(), ya.cpu().numpy()) < 2e-6
+        assert rel_l2(yb2.cpu().numpy(), yb.cpu().numpy()) < 2e-6
+        assert torch.equal(fa2, fa)  # the gather has no atomics
+    from torch_nfft_amd import ops
+    ops.check_status()
