@@ -363,7 +363,7 @@ def main():
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = n_gpus * n / (elapsed / args.steps) / 1e6
-        # dominant kernel: the spreading kernel (stage "spread" = one launch of it per step, plus its empty overflow
+        # dominant kernel: the spreading kernel (stage "spread" = one launch of it per step, plus its empty work-list
         # launch): the matrix-core kernel for 3-D grids of 64^3 and up with m <= 7, else spread_kernel
         W = 2 * m + 2
         mfma = d == 3 and M >= 64 and W <= 16 and os.environ.get("NFFT_HIP_SPREAD", "m")[:1] not in ("l", "r")

@@ -84,9 +84,9 @@ def test_config_c3_3d_n256_m4_10m(tn):
     assert rel_l2((y + 2 * y2).cpu().numpy(), y12.cpu().numpy()) < 2e-6
 
 
-def test_clustered_points_overflow_launch(tn):
+def test_clustered_points_work_list(tn):
     """2e6 points in 8 Gaussian clusters (sigma 0.05; SURVEY 8(d)'s robustness distribution) on a 256^3 grid, two point
-    sets: dense slab ranges are cut at plan time and their extra pieces run in the second (overflow) launch of the
+    sets: dense slab ranges are cut at plan time and all pieces run from the plan's work list in the persistent launch of the
     matrix-core kernels.  Adjoint on a frequency subset vs the exact NDFT, forward of a sparse spectrum vs the exact
     sum, adjointness between the two."""
     N, m, n = 128, 4, 2_000_000
@@ -125,7 +125,7 @@ def test_clustered_points_overflow_launch(tn):
 
 def test_config_c3_clustered_10m(tn):
     """bench.py's `C3-clustered` leg at its full size: 3-D N=256, m=4, 10^7 points in 8 Gaussian clusters (sigma 0.05,
-    SURVEY.md 8(d)'s second distribution) -- dense slab ranges cut into overflow pieces, over-full slabs, the streamed
+    SURVEY.md 8(d)'s second distribution) -- dense slab ranges cut into pieces (the plan's work list), over-full slabs, the streamed
     gather on ragged work items.  Adjoint on a frequency subset vs the exact NDFT, forward of a sparse spectrum vs the
     exact sum, adjointness between the two, and no device fault left behind."""
     from torch_nfft_amd import ops
@@ -278,7 +278,7 @@ def test_config_c5_fastsum_1m_x_1m(tn):
 
 def test_streamed_interpolation_clustered_8m(tn):
     """8e6 points in 8 tight Gaussian clusters on a 256^3 grid: the plan's work items are big enough for the streamed
-    (producer / consumer) interpolation kernel, most of them are overflow pieces, many chunks between clusters are
+    (producer / consumer) interpolation kernel, most of them are cut pieces, many chunks between clusters are
     empty (the producers skip planes nobody needs).  Forward of a sparse spectrum vs the exact sums on a sample of
     points, run twice (the kernel has no atomics: the two runs must agree bitwise), and adjointness with the adjoint."""
     N, m, n = 128, 4, 8_000_000

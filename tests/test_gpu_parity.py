@@ -223,7 +223,7 @@ def test_edge_cases_wide_tiling(tn, N, m):
 
 def test_many_small_point_sets_wide_tiling(tn):
     """1 500 point sets of a few points each on a 64^3 grid: more first-level sort bins than fit the LDS histogram, so
-    the plan takes the one-level (global-atomic) binning path -- without the overflow list -- under the matrix-core
+    the plan takes the one-level (global-atomic) binning path -- its work list is built from the one-level bins -- under the matrix-core
     kernels; checked on a sample of the point sets against the oracle."""
     rng = np.random.default_rng(123)
     B, N, m = 1500, 32, 3
@@ -709,7 +709,7 @@ print("RESULT", np.linalg.norm((got - ref).ravel()) / np.linalg.norm(ref.ravel()
 @pytest.mark.parametrize("owned", ["0", "1"])
 def test_owned_and_scatter_spreading_agree_dense_clustered(owned):
     """NFFT_HIP_OWNED forces either spreading variant whatever the density: 600 000 points, half of them in two tight
-    clusters (dense slab ranges are cut into overflow pieces) and one cluster on the periodic corner, two point sets,
+    clusters (dense slab ranges are cut into pieces: the work list) and one cluster on the periodic corner, two point sets,
     128^3 grid -- adjoint on a frequency subset vs the exact NDFT and vs the float64 algorithm restatement."""
     import subprocess
     import sys
@@ -788,7 +788,7 @@ def test_streamed_gather_and_column_groups_on_small_problems(env_extra):
     """The streamed gather and the column-group order of the plan are chosen for big work items only; with
     NFFT_HIP_STREAM_MIN=1 they run on problems the oracle can check.  Every cutoff of the wide tiling (chunks of 13 ... 1
     slabs, windows of 4 ... 16 taps), grids whose last pencil is partial, points on pencil and group boundaries, a dense
-    cluster (overflow pieces), empty regions, two point sets: adjoint and forward vs the float64 oracle.  The third case
+    cluster (cut pieces), empty regions, two point sets: adjoint and forward vs the float64 oracle.  The third case
     runs the coefficient permutation as a pass of its own (the default does it inside the spreading kernel)."""
     import subprocess
     import sys

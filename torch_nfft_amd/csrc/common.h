@@ -397,6 +397,14 @@ inline int seg_base_runs(int64_t n, int64_t nsets, int64_t pencils, int M, int n
     r = r < lo ? lo : (r > hi ? hi : r);
     return (int)(r > kSegMax ? kSegMax : r);
 }
+// Workgroups of the persistent launch over a plan's work list: one per CU, but no more than a point set can have entries
+// (its ranges plus one cut per `target` points) -- a batch of many small point sets launches a few per plane, not 256.
+inline unsigned work_list_workgroups(int64_t n, int64_t nsets, int64_t pencils, int runs, int ncu)
+{
+    const int64_t most = pencils * runs + n / seg_target_points(n, nsets, ncu) + 1;
+    const int64_t cus = ncu > 0 ? (ncu < 1024 ? ncu : 1024) : 256;
+    return (unsigned)(most < cus ? (most < 1 ? 1 : most) : cus);
+}
 // Work items big enough for the streamed gather (interp_stream.hip: its pipeline costs ~10 us of warm-up and tail per
 // item): 7 237 points per item at config C3, the minimum of 2 048 at C5, where the lock-step kernel stays ahead
 // (0.60 vs 0.83 ms); at 5e6 points (3 617 per item) the streamed kernel + column groups win by 0.1 ms per step.

@@ -356,7 +356,7 @@ static int launch_ic_t(const Geom &g, const PlanLayout &L, const void *plan, con
     // the persistent launch over the work list (unbalanced plans; its workgroups leave at once otherwise); entries are
     // handed out by tickets when the launch's planes fit its share of the ticket ring, else round robin
     const WorkTickets tickets{ngroups <= kTicketPlanes ? device_ticket_ring() : nullptr, next_launch_number()};
-    const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)ngroups);
+    const dim3 oblocks(work_list_workgroups(n, nsets, pencils, nsegm, device_cu_count()), (unsigned)ngroups);
     hipLaunchKernelGGL((interp_cols_kernel<W, true>), oblocks, dim3(kIcThreads), sizeof(IcLds), stream, g, to,
                        spos, grid, (int)Cr, plane0, nplanes, group0, yr, seg_slabs, nsegm, work, sorted, tickets);
     NFFT_HIP_CHECK(hipGetLastError());

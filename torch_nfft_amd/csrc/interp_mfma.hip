@@ -59,7 +59,7 @@ interp_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets,
     const int cr = plane - b * Cr;
     const int pencils = g.nta[1] * g.nta[2];
 
-    // ---- work items: the same ranges of slabs (and, for dense ranges, pieces from the plan's overflow list) as the
+    // ---- work items: the same ranges of slabs (or, for unbalanced plans, the entries of the plan's work list) as the
     // spreading kernel (spread_mfma.hip); an item owns the chunks whose first slab lies in its range.
     // (work items as in spread_mfma.hip: one workgroup per range, or a persistent grid over the plan's work list)
     const int listed = work[0].z;
@@ -271,7 +271,7 @@ static int launch_gm_t(const Geom &g, const PlanLayout &L, const void *plan, con
                        const float *spos, const float *grid, int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes,
                        float *yr, hipStream_t stream)
 {
-    // the work decomposition of the spreading kernel (ranges of M / runs slabs per pencil + the plan's overflow list
+    // the work decomposition of the spreading kernel (ranges of M / runs slabs per pencil + the plan's work list
     // for dense ranges); every item starts by staging all 16 planes of its first chunk
     const int64_t pencils = (int64_t)g.nta[1] * g.nta[2];
     int64_t nsets = g.tiles_per_batch > 0 ? L.ntiles / g.tiles_per_batch : 1;
@@ -294,7 +294,7 @@ static int launch_gm_t(const Geom &g, const PlanLayout &L, const void *plan, con
     // the persistent launch over the work list (unbalanced plans; its workgroups leave at once otherwise); entries are
     // handed out by tickets when the launch's planes fit its share of the ticket ring, else round robin
     const WorkTickets tickets{nplanes <= kTicketPlanes ? device_ticket_ring() : nullptr, next_launch_number()};
-    const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
+    const dim3 oblocks(work_list_workgroups(n, nsets, pencils, nsegm, device_cu_count()), (unsigned)nplanes);
     hipLaunchKernelGGL((interp_mfma_kernel<W, true>), oblocks, dim3(kGmThreads), sizeof(GatherMfmaLds), stream, g,
                        to, spos, grid, (int)Cr, (int)plane0, yr, seg_slabs, nsegm, work, sorted, tickets);
     NFFT_HIP_CHECK(hipGetLastError());

@@ -37,9 +37,8 @@ bool small1d_supported(const nfft_hip_problem *p)
 
 namespace {
 
-// LDS (dynamic): [ double2 acc[M] | float2 buf[M] | float2 twiddle[M / 2] | 2 ints ]; the FFT ping-pongs between `buf`
-// and the (by then free) accumulator area.
-__device__ __forceinline__ size_t s1_lds_bytes(int M) { return (size_t)M * 16 + (size_t)M * 8 + (size_t)M * 4 + 16; }
+// LDS (dynamic, M * 28 + 16 bytes): [ double2 acc[M] | float2 buf[M] | float2 twiddle[M / 2] | 2 x int64 ]; the FFT
+// ping-pongs between `buf` and the (by then free) accumulator area.
 
 // rows [lo, hi) of point set b in the sorted batch vector (nullptr: one set)
 __device__ __forceinline__ void set_range(const int64_t *__restrict__ batch, int64_t n, int64_t b, int64_t &lo, int64_t &hi)

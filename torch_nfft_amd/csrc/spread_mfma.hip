@@ -717,7 +717,7 @@ static int launch_mfma_t(const Geom &g, const PlanLayout &L, const void *plan, c
     // the persistent launch over the work list (unbalanced plans; its workgroups leave at once otherwise); entries are
     // handed out by tickets when the launch's planes fit its share of the ticket ring, else round robin
     const WorkTickets tickets{nplanes <= kTicketPlanes ? device_ticket_ring() : nullptr, next_launch_number()};
-    const dim3 oblocks((unsigned)std::min(device_cu_count(), 1024), (unsigned)nplanes);
+    const dim3 oblocks(work_list_workgroups(n, nsets, pencils, nsegm, device_cu_count()), (unsigned)nplanes);
     hipLaunchKernelGGL((spread_mfma_kernel<W, true, OWNED>), oblocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to,
                        spos, xr, xs, L.cap, xmax, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, work, sorted, tickets, status);
     NFFT_HIP_CHECK(hipGetLastError());
