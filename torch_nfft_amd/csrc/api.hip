@@ -134,8 +134,8 @@ int *device_status_block()
 }
 
 // Ticket counters of the persistent launches over a plan's work list (common.h: WorkTickets): a ring of 64-bit words
-// {launch number, tickets taken} per device, zeroed once.  A launch owns the 256 words of its number modulo 256 -- one per
-// plane -- and claims a word by overwriting whatever an earlier launch (256 launches ago: long finished) left there, so
+// {launch number, tickets taken} per device, zeroed once.  A launch owns the 256 words of its number modulo 4096 -- one per
+// plane -- and claims a word by overwriting whatever an earlier launch (4096 launches ago: long finished) left there, so
 // nothing is reset between launches and the plan itself stays read-only (it may be in use on several streams).
 unsigned long long *device_ticket_ring()
 {

@@ -112,7 +112,9 @@ struct Geom {
 };
 
 inline bool owned_supported(int dim, int64_t N, int64_t m);
-constexpr int kTicketPlanes = 256, kTicketLaunches = 256, kTicketSlots = kTicketPlanes * kTicketLaunches;
+// (4096 launch numbers before a row of the ring is used again: a launch would have to outlive 4096 later ones -- on other
+// streams -- for two to meet in a row; 8 MB per device)
+constexpr int kTicketPlanes = 256, kTicketLaunches = 4096, kTicketSlots = kTicketPlanes * kTicketLaunches;
 unsigned long long *device_ticket_ring();  // api.hip: per-device ring of ticket words (WorkTickets below); nullptr on failure
 unsigned next_launch_number();             // api.hip: process-wide, never 0
 bool work_list_forced();       // api.hip: NFFT_HIP_WORK_LIST=1 runs every wide plan from its work list
