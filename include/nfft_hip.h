@@ -96,8 +96,8 @@ int nfft_hip_forward(const nfft_hip_problem *p, const float *pos, const void *xh
                      const int64_t *batch, int real_output, void *y,
                      void *workspace, int64_t workspace_bytes, void *stream);
 
-/* 0 when the library runs this problem WITHOUT a point plan: 1-D problems whose oversampled grid (2N cells, a power of
- * two up to 4096) fits one workgroup's LDS and whose point sets are small run nfft_hip_adjoint / nfft_hip_forward as one
+/* 0 when the library runs this problem WITHOUT a point plan: problems whose oversampled grid ((2N)^dim cells, 2N a power
+ * of two, at most 4096 cells) fits one workgroup's LDS and whose point sets are small run nfft_hip_adjoint / nfft_hip_forward as one
  * kernel each -- workspace may be NULL for them, and building a plan for the *_planned entry points would only add five
  * launches.  1 otherwise (callers that transform the same points repeatedly then build the plan once).  No reference
  * counterpart: the reference recomputes shifts and window values in every call (core_cuda.cu:188-211). */

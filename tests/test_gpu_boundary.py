@@ -134,7 +134,7 @@ def test_c_abi_matrix_core_grid_unplanned(tn):
 @pytest.mark.parametrize("d,N,shared,complex_x,complex_coeffs", [(2, 16, True, False, False), (2, 16, False, True, True),
                                                                    (3, 32, False, False, True), (3, 32, True, True, False),
                                                                    (1, 64, False, False, False),
-                                                                   # 1-D, grid in LDS: two fused kernels (small1d.hip)
+                                                                   # 1-D, grid in LDS: two fused kernels (smallgrid.hip)
                                                                    (1, 64, True, True, True), (1, 512, False, True, False),
                                                                    (1, 100, False, True, True)])  # (200 cells: general path)
 def test_c_abi_fastsum(tn, d, N, shared, complex_x, complex_coeffs):

@@ -113,7 +113,7 @@ def _random_problem(rng, d, n, B, cols, complex_x):
 @pytest.mark.parametrize("d,N,m", [(1, 64, 2), (1, 32, 3), (1, 512, 4), (2, 16, 3), (2, 32, 4), (2, 64, 2),
                                    (3, 16, 4), (3, 16, 2), (3, 24, 3), (3, 32, 4), (2, 16, 6), (3, 16, 5),
                                    (1, 64, 8), (2, 32, 8), (3, 20, 7), (2, 8, 1),
-                                   (1, 48, 3), (1, 100, 4), (1, 4096, 2)])  # (1-D outside the fused path: small1d.hip)
+                                   (1, 48, 3), (1, 100, 4), (1, 4096, 2)])  # (1-D outside the fused path: smallgrid.hip)
 @pytest.mark.parametrize("complex_x", [False, True])
 def test_adjoint_and_forward_vs_oracle(tn, d, N, m, complex_x):
     rng = np.random.default_rng(1000 * d + N + m)
@@ -412,22 +412,23 @@ def test_full_rocfft_path_when_column_passes_disabled(tn, monkeypatch):
 
 
 def test_plan_cache_follows_in_place_updates(tn):
-    """The host keeps one point plan keyed on tensor identity + version; editing pos in place must re-plan."""
+    """The host keeps one point plan keyed on tensor identity + version; editing pos in place must re-plan.  (A 128^2 grid:
+    smaller ones run without a plan, smallgrid.hip.)"""
     from torch_nfft_amd import ops
     rng = np.random.default_rng(91)
     pos, _, x = _random_problem(rng, 2, 300, 1, (), False)
     post, xt = dev(pos), dev(x)
     ops.plan_cache_clear()
-    y1 = tn.nfft_adjoint(xt, post, None, bandwidth=16, cutoff=3)
+    y1 = tn.nfft_adjoint(xt, post, None, bandwidth=64, cutoff=3)
     h0 = ops.plan_cache_stats()["hits"]
-    y1b = tn.nfft_adjoint(xt, post, None, bandwidth=16, cutoff=3)
+    y1b = tn.nfft_adjoint(xt, post, None, bandwidth=64, cutoff=3)
     assert ops.plan_cache_stats()["hits"] == h0 + 1
     assert rel_l2(host(y1b), host(y1)) < 1e-6
     post.mul_(0.5)  # in-place: version counter changes
-    y2 = tn.nfft_adjoint(xt, post, None, bandwidth=16, cutoff=3)
-    assert rel_l2(host(y2), nfft_ref.nfft_adjoint(x, pos * 0.5, None, N=16, m=3)) < T1
+    y2 = tn.nfft_adjoint(xt, post, None, bandwidth=64, cutoff=3)
+    assert rel_l2(host(y2), nfft_ref.nfft_adjoint(x, pos * 0.5, None, N=64, m=3)) < T1
     ops.plan_cache_enabled(False)
-    y3 = tn.nfft_adjoint(xt, post, None, bandwidth=16, cutoff=3)
+    y3 = tn.nfft_adjoint(xt, post, None, bandwidth=64, cutoff=3)
     ops.plan_cache_enabled(True)
     assert rel_l2(host(y3), host(y2)) < 1e-6
 

@@ -1,8 +1,10 @@
-"""GPU parity of the fused 1-D path (csrc/small1d.hip): 1-D transforms whose oversampled grid fits one workgroup's LDS
-run as ONE kernel per direction on the caller's points, without a point plan.  Checked against the oracle
+"""GPU parity of the fused small-grid path (csrc/smallgrid.hip): transforms whose oversampled grid fits one workgroup's
+LDS (<= 4096 cells: 1-D N <= 2048, 2-D N <= 32, 3-D N <= 8) run as ONE kernel per direction on the caller's points,
+without a point plan.  Checked against the oracle
 (oracle/nfft_ref.py = the reference's algorithm in float64; oracle/ndft.py = the exact sums) and against the general path
 (point plan -> spreading -> rocFFT -> roll-off) through the planned C entry points on the same inputs."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -40,10 +42,10 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _problem(rng, n, sizes, cols, complex_x):
+def _problem(rng, n, sizes, cols, complex_x, d=1):
     """points on the torus incl. both ends of [-1/2, 1/2) and a cell boundary; `sizes` = points per point set"""
-    pos = (rng.random((n, 1)) - 0.5).astype(np.float32)
-    pos[:4, 0] = (-0.5, np.nextafter(np.float32(0.5), np.float32(0)), 0.0, 0.25)
+    pos = (rng.random((n, d)) - 0.5).astype(np.float32)
+    pos[:4, :] = np.array((-0.5, np.nextafter(np.float32(0.5), np.float32(0)), 0.0, 0.25), dtype=np.float32)[:, None]
     batch = None if sizes is None else np.repeat(np.arange(len(sizes)), sizes).astype(np.int64)
     x = rng.standard_normal((n,) + cols).astype(np.float32)
     if complex_x:
@@ -61,26 +63,32 @@ def test_plan_needed_says_which_problems_are_fused(tn):
     assert need(1, 1000, 1, 100, 4) == 1         # 200 cells: not a power of two
     assert need(1, 10 ** 6, 1, 64, 2) == 1       # too many points for one workgroup
     assert need(1, 10 ** 5, 8, 64, 2) == 0       # ... but fine over 8 point sets
-    assert need(2, 1000, 1, 64, 2) == 1 and need(3, 1000, 1, 16, 2) == 1
+    assert need(2, 1000, 1, 32, 4) == 0 and need(3, 500, 1, 8, 2) == 0   # 64^2 and 16^3 cells
+    assert need(2, 1000, 1, 64, 2) == 1 and need(3, 1000, 1, 16, 2) == 1 # 128^2, 32^3 cells
+    assert need(2, 10 ** 5, 1, 32, 4) == 1                               # 10^7 window taps in one workgroup
 
 
-@pytest.mark.parametrize("N,m", [(2, 1), (8, 2), (64, 2), (64, 8), (512, 4), (2048, 3)])
+@pytest.mark.parametrize("d,N,m", [(1, 2, 1), (1, 8, 2), (1, 64, 2), (1, 64, 8), (1, 512, 4), (1, 2048, 3),
+                                   (2, 2, 1), (2, 4, 3), (2, 16, 3), (2, 16, 4), (2, 32, 8), (2, 32, 1),
+                                   (3, 2, 1), (3, 4, 2), (3, 8, 2), (3, 8, 7)])
 @pytest.mark.parametrize("complex_x", [False, True])
-def test_fused_1d_vs_oracle(tn, N, m, complex_x):
+def test_fused_vs_oracle(tn, d, N, m, complex_x):
     """three point sets (the middle one EMPTY), two columns, both directions, complex and real_output results"""
-    rng = np.random.default_rng(9000 + N + m)
-    sizes = [311, 0, 402]
+    from torch_nfft_amd import _lib
+    rng = np.random.default_rng(9000 + 100 * d + N + m)
+    sizes = [311, 0, 402] if d < 3 or m < 5 else [150, 0, 130]
     n, B, cols = sum(sizes), 3, (2,)
-    pos, batch, x = _problem(rng, n, sizes, cols, complex_x)
+    assert _lib.load().nfft_hip_plan_needed(ctypes.byref(_lib.Problem(d, n, 2, B, N, m))) == 0
+    pos, batch, x = _problem(rng, n, sizes, cols, complex_x, d)
     for real_output in (False, True):
         ya = tn.nfft_adjoint(dev(x), dev(pos), dev(batch), bandwidth=N, cutoff=m, real_output=real_output)
-        assert ya.shape == (B, N) + cols and ya.dtype == (torch.float32 if real_output else torch.complex64)
+        assert ya.shape == (B,) + (N,) * d + cols and ya.dtype == (torch.float32 if real_output else torch.complex64)
         assert rel_l2(host(ya), nfft_ref.nfft_adjoint(x, pos, batch, N=N, m=m, real_output=real_output)) < T1N
         assert float(ya[1].abs().max()) == 0.0  # the empty point set
     if N >= 8:  # (the window is wider than a 4-cell grid: the NFFT itself is no approximation of the NDFT there)
         assert rel_l2(host(tn.nfft_adjoint(dev(x), dev(pos), dev(batch), bandwidth=N, cutoff=m)),
                       ndft.ndft_adjoint(x, pos, batch, N=N)) < T2[m]
-    xh = rng.standard_normal((B, N) + cols).astype(np.float32)
+    xh = rng.standard_normal((B,) + (N,) * d + cols).astype(np.float32)
     if complex_x:
         xh = (xh + 1j * rng.standard_normal(xh.shape)).astype(np.complex64)
     for real_output in (False, True):
@@ -91,24 +99,25 @@ def test_fused_1d_vs_oracle(tn, N, m, complex_x):
         assert rel_l2(host(tn.nfft_forward(dev(xh), dev(pos), dev(batch), cutoff=m)), ndft.ndft_forward(xh, pos, batch)) < T2[m]
 
 
-@pytest.mark.parametrize("N,m,B", [(64, 2, 1), (256, 4, 4), (2048, 6, 2)])
-def test_fused_and_general_path_agree(tn, N, m, B):
+@pytest.mark.parametrize("d,N,m,B", [(1, 64, 2, 1), (1, 256, 4, 4), (1, 2048, 6, 2), (2, 16, 4, 3), (2, 32, 3, 1), (3, 8, 2, 2),
+                                     (3, 8, 4, 1)])
+def test_fused_and_general_path_agree(tn, d, N, m, B):
     """nfft_hip_adjoint / nfft_hip_forward (fused) against nfft_hip_plan_points + the *_planned entry points (the general
     path, which ignores nfft_hip_plan_needed) on the same device buffers."""
     from torch_nfft_amd import _lib
     lib = _lib.load()
-    rng = np.random.default_rng(31 + N)
-    n, C = 5000, 3
+    rng = np.random.default_rng(31 + N + d)
+    n, C = {1: 5000, 2: 1500, 3: 500}[d], 3  # (3-D, m = 4: 1000 window taps per point; 6e5 per set is the fused path's limit)
     sizes = None if B == 1 else list(rng.multinomial(n, np.ones(B) / B))
-    pos, batch, x = _problem(rng, n, sizes, (C,), True)
-    prob = _lib.Problem(1, n, C, B, N, m)
+    pos, batch, x = _problem(rng, n, sizes, (C,), True, d)
+    prob = _lib.Problem(d, n, C, B, N, m)
     P = ctypes.byref(prob)
     assert lib.nfft_hip_plan_needed(P) == 0
     pt, bt, xt = dev(pos), dev(batch), dev(x)
     plan = torch.empty(lib.nfft_hip_plan_bytes(P), dtype=torch.uint8, device="cuda")
     _lib.check(lib.nfft_hip_plan_points(P, _p(pt), _p(bt), _p(plan), plan.numel(), _stream()))
     wsa = torch.empty(lib.nfft_hip_adjoint_workspace_bytes(P, 1, 0), dtype=torch.uint8, device="cuda")
-    y_fused = torch.full((B, N, C), float("nan"), dtype=torch.complex64, device="cuda")
+    y_fused = torch.full((B,) + (N,) * d + (C,), float("nan"), dtype=torch.complex64, device="cuda")
     y_general = torch.full_like(y_fused, float("nan"))
     _lib.check(lib.nfft_hip_adjoint(P, _p(pt), _p(xt), 1, _p(bt), 0, _p(y_fused), None, 0, _stream()))  # no workspace
     _lib.check(lib.nfft_hip_adjoint_planned(P, _p(plan), _p(xt), 1, 0, _p(y_general), _p(wsa), wsa.numel(), _stream()))
@@ -121,7 +130,7 @@ def test_fused_and_general_path_agree(tn, N, m, B):
     assert rel_l2(host(f_fused), host(f_general)) < T1N
 
 
-def test_fused_1d_empty_input_and_faults(tn):
+def test_fused_empty_input_and_faults(tn):
     from torch_nfft_amd import _lib, ops
     lib = _lib.load()
     # no points: the adjoint is all zeros, the forward transform an empty tensor
@@ -148,7 +157,7 @@ def test_fused_1d_empty_input_and_faults(tn):
     assert rel_l2(host(yt), ref) < T1N
 
 
-def test_fused_1d_pair_is_adjoint(tn):
+def test_fused_pair_is_adjoint(tn):
     """the two fused kernels are each other's transposes (same window, same roll-off): <A x, w> == <x, A^H w>, and the
     autograd backward of one is the other (reference: nfft.py:22-28, 48-54)"""
     rng = np.random.default_rng(77)
@@ -165,3 +174,37 @@ def test_fused_1d_pair_is_adjoint(tn):
     (tn.nfft_adjoint(xr, dev(pos), None, bandwidth=N, cutoff=m, real_output=True) * wr).sum().backward()
     expect = tn.nfft_forward(wr, dev(pos), None, cutoff=m, real_output=True)
     assert rel_l2(host(xr.grad), host(expect)) < 1e-5
+
+
+def test_general_path_on_small_grids():
+    """NFFT_HIP_SMALL_GRID=0 turns the fused path off: the same small problems through point plan -> LDS-tile spreading ->
+    rocFFT / the pruned column passes (16^3 cells) -> roll-off -> gather, against the oracle (these sizes reach the general
+    path only this way since the fused kernels exist)."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+import torch_nfft_amd as tn
+from oracle import nfft_ref
+worst = 0.0
+for d, N, m in ((1, 64, 2), (1, 32, 3), (1, 512, 4), (2, 16, 3), (2, 32, 4), (2, 8, 1), (2, 16, 6), (3, 8, 2), (3, 8, 4), (3, 4, 1)):
+    rng = np.random.default_rng(1000 * d + N + m)
+    n, B = 700, 3
+    pos = (rng.random((n, d)) - 0.5).astype(np.float32)
+    batch = np.sort(rng.integers(0, B, n)).astype(np.int64); batch[0], batch[-1] = 0, B - 1
+    x = (rng.standard_normal((n, 2)) + 1j * rng.standard_normal((n, 2))).astype(np.complex64)
+    xt, pt, bt = torch.from_numpy(x).cuda(), torch.from_numpy(pos).cuda(), torch.from_numpy(batch).cuda()
+    y = tn.nfft_adjoint(xt, pt, bt, bandwidth=N, cutoff=m)
+    ref = nfft_ref.nfft_adjoint(x, pos, batch, N=N, m=m)
+    worst = max(worst, np.linalg.norm(y.cpu().numpy() - ref) / np.linalg.norm(ref))
+    f = tn.nfft_forward(y, pt, bt, cutoff=m, real_output=True)
+    reff = nfft_ref.nfft_forward(y.cpu().numpy(), pos, batch, m=m, real_output=True)
+    worst = max(worst, np.linalg.norm(f.cpu().numpy() - reff) / np.linalg.norm(reff))
+print("RESULT", worst)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NFFT_HIP_SMALL_GRID="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    assert float(line[1]) < 2e-5

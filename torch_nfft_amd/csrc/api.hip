@@ -584,13 +584,13 @@ static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64
     if (int rc = take_pending_fault()) return rc;  // a kernel of an earlier call gave up: say so
     if (int rc = validate(p)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if (!ext_plan && small1d_supported(p)) {
-        // 1-D, grid in one workgroup's LDS: one kernel, no plan, no workspace (small1d.hip)
+    if (!ext_plan && small_grid_supported(p)) {
+        // grid in one workgroup's LDS: one kernel, no plan, no workspace (smallgrid.hip)
         if (p->batch_size * p->num_columns == 0) return 0;
         if (!y) { set_error("Input mismatch: y is null"); return NFFT_HIP_EINVAL; }
         if (p->num_points > 0 && (!pos || !x)) { set_error("Input mismatch: null input"); return NFFT_HIP_EINVAL; }
         StageTimer t(kStageSpread, s);
-        return launch_small1d_adjoint(p, pos, batch, x, x_is_complex, real_output, y, mult, mult_kind, s);
+        return launch_small_grid_adjoint(p, pos, batch, x, x_is_complex, real_output, y, mult, mult_kind, s);
     }
     const int ppc = x_is_complex ? 2 : 1;
     Carve c;
@@ -664,11 +664,11 @@ static int forward_impl(const nfft_hip_problem *p, const float *pos, const int64
     if (int rc = take_pending_fault()) return rc;  // a kernel of an earlier call gave up: say so
     if (int rc = validate(p)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if (!ext_plan && small1d_supported(p)) {
+    if (!ext_plan && small_grid_supported(p)) {
         if (p->batch_size * p->num_columns == 0 || p->num_points == 0) return 0;
         if (!y || !pos || !xhat) { set_error("Input mismatch: null input"); return NFFT_HIP_EINVAL; }
         StageTimer t(kStageInterp, s);
-        return launch_small1d_forward(p, pos, batch, xhat, x_is_complex, real_output, y, s);
+        return launch_small_grid_forward(p, pos, batch, xhat, x_is_complex, real_output, y, s);
     }
     const int ppc = real_output ? 1 : 2;
     Carve c;
@@ -735,7 +735,7 @@ int nfft_hip_forward(const nfft_hip_problem *p, const float *pos, const void *xh
 int nfft_hip_plan_needed(const nfft_hip_problem *p)
 {
     if (validate(p)) return 1;
-    return small1d_supported(p) ? 0 : 1;
+    return small_grid_supported(p) ? 0 : 1;
 }
 
 int nfft_hip_adjoint_planned(const nfft_hip_problem *p, const void *plan, const void *x, int x_is_complex,
@@ -811,9 +811,9 @@ int fastsum_impl(const nfft_hip_problem *src_in, const float *sources, const int
     if (!workspace || workspace_bytes < f.total) { set_error("workspace too small"); return NFFT_HIP_EWORKSPACE; }
     char *ws = (char *)(((uintptr_t)workspace + 255) & ~uintptr_t(255));
     hipStream_t s = (hipStream_t)stream;
-    // 1-D problems whose grid fits one workgroup's LDS: adjoint (with the kernel's coefficients folded into its roll-off)
-    // and forward transform are one fused kernel each on the caller's points -- no plans (small1d.hip)
-    const bool fused1d = own_plans && small1d_supported(src) && small1d_supported(tgt);
+    // problems whose grid fits one workgroup's LDS: adjoint (with the kernel's coefficients folded into its roll-off)
+    // and forward transform are one fused kernel each on the caller's points -- no plans (smallgrid.hip)
+    const bool fused1d = own_plans && small_grid_supported(src) && small_grid_supported(tgt);
     if (fused1d) {
         if (src->num_points > 0 && !sources) { set_error("Input mismatch: sources is null"); return NFFT_HIP_EINVAL; }
         if (!targets) { set_error("Input mismatch: targets is null"); return NFFT_HIP_EINVAL; }

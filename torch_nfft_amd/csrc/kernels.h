@@ -105,11 +105,12 @@ int launch_row_r2c(const Geom &g, const float *grid, void *scratch, int64_t scra
 int launch_row_c2r(const Geom &g, const float2 *spec, void *scratch, int64_t scratch_planes, int64_t nplanes,
                    float *grid, hipStream_t stream);
 
-// small1d.hip: 1-D transforms whose oversampled grid fits one workgroup's LDS -- one kernel per direction, no point plan
-bool small1d_supported(const nfft_hip_problem *p);
-int launch_small1d_adjoint(const nfft_hip_problem *p, const float *pos, const int64_t *batch, const void *x, int x_is_complex,
+// smallgrid.hip: transforms whose oversampled grid (<= 4096 cells) fits one workgroup's LDS -- one kernel per direction,
+// no point plan
+bool small_grid_supported(const nfft_hip_problem *p);
+int launch_small_grid_adjoint(const nfft_hip_problem *p, const float *pos, const int64_t *batch, const void *x, int x_is_complex,
                            int real_output, void *y, const void *mult, int mult_kind, hipStream_t stream);
-int launch_small1d_forward(const nfft_hip_problem *p, const float *pos, const int64_t *batch, const void *xhat, int x_is_complex,
+int launch_small_grid_forward(const nfft_hip_problem *p, const float *pos, const int64_t *batch, const void *xhat, int x_is_complex,
                            int real_output, void *y, hipStream_t stream);
 
 // api.hip: optional per-stage GPU timing with HIP events on the caller's stream (nfft_hip_profile_*)
