@@ -61,11 +61,11 @@ def test_plan_needed_says_which_problems_are_fused(tn):
     assert need(1, 1000, 1, 2048, 8) == 0        # 4096 cells: the largest fused grid
     assert need(1, 1000, 1, 4096, 4) == 1        # 8192 cells
     assert need(1, 1000, 1, 100, 4) == 1         # 200 cells: not a power of two
-    assert need(1, 10 ** 6, 1, 64, 2) == 1       # too many points for one workgroup
-    assert need(1, 10 ** 5, 8, 64, 2) == 0       # ... but fine over 8 point sets
-    assert need(2, 1000, 1, 32, 4) == 0 and need(3, 500, 1, 8, 2) == 0   # 64^2 and 16^3 cells
+    assert need(1, 10 ** 5, 1, 64, 2) == 1       # 6e5 window taps: too many for one workgroup
+    assert need(1, 7 * 10 ** 4, 8, 64, 2) == 0   # ... but fine over 8 point sets
+    assert need(2, 500, 1, 32, 4) == 0 and need(3, 200, 1, 8, 2) == 0    # 64^2 and 16^3 cells
     assert need(2, 1000, 1, 64, 2) == 1 and need(3, 1000, 1, 16, 2) == 1 # 128^2, 32^3 cells
-    assert need(2, 10 ** 5, 1, 32, 4) == 1                               # 10^7 window taps in one workgroup
+    assert need(2, 1000, 1, 32, 4) == 1 and need(2, 500, 1, 32, 4) == 0   # 10^5 / 5e4 window taps in one workgroup
 
 
 @pytest.mark.parametrize("d,N,m", [(1, 2, 1), (1, 8, 2), (1, 64, 2), (1, 64, 8), (1, 512, 4), (1, 2048, 3),
@@ -76,7 +76,10 @@ def test_fused_vs_oracle(tn, d, N, m, complex_x):
     """three point sets (the middle one EMPTY), two columns, both directions, complex and real_output results"""
     from torch_nfft_amd import _lib
     rng = np.random.default_rng(9000 + 100 * d + N + m)
-    sizes = [311, 0, 402] if d < 3 or m < 5 else [150, 0, 130]
+    # (the fused path takes at most 6e4 window taps per point set on average: fewer points for the wide windows)
+    taps = (2 * m + 2) ** d
+    big = max(2, min(402, int(0.55 * 180000 // taps)))
+    sizes = [max(1, int(0.77 * big)), 0, big]
     n, B, cols = sum(sizes), 3, (2,)
     assert _lib.load().nfft_hip_plan_needed(ctypes.byref(_lib.Problem(d, n, 2, B, N, m))) == 0
     pos, batch, x = _problem(rng, n, sizes, cols, complex_x, d)
@@ -107,7 +110,7 @@ def test_fused_and_general_path_agree(tn, d, N, m, B):
     from torch_nfft_amd import _lib
     lib = _lib.load()
     rng = np.random.default_rng(31 + N + d)
-    n, C = {1: 5000, 2: 1500, 3: 500}[d], 3  # (3-D, m = 4: 1000 window taps per point; 6e5 per set is the fused path's limit)
+    n, C = int(0.9 * 60000 * min(B, 8) // (2 * m + 2) ** d), 3  # (6e4 window taps per set is the fused path's limit)
     sizes = None if B == 1 else list(rng.multinomial(n, np.ones(B) / B))
     pos, batch, x = _problem(rng, n, sizes, (C,), True, d)
     prob = _lib.Problem(d, n, C, B, N, m)

@@ -18,9 +18,12 @@
 
 namespace nfft {
 
-constexpr int kSgThreads = 256;
+constexpr int kSgThreads = 1024;          // (16 waves: the LDS atomics and reads of the tap loops are latency-bound with fewer)
 constexpr int kSgMaxCells = 4096;         // grid cells: 16 B of fp64 sums + 8 B of FFT buffer per cell (+ twiddles)
-constexpr int64_t kSgMaxSetTaps = 600000; // average window taps per point set (a set is one workgroup's serial loop)
+// average window taps per point set: a set is ONE workgroup's loop, ~0.35 ns per tap and direction (LDS atomics of a single
+// CU) on top of ~25 us per adjoint + forward pair, against 80-145 us for the general path on these sizes -- measured
+// break-even ~10^5 taps (profiles/r03_experiments.md)
+constexpr int64_t kSgMaxSetTaps = 60000;
 
 bool small_grid_supported(const nfft_hip_problem *p)
 {
