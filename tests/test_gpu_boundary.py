@@ -217,6 +217,35 @@ def test_negative_batch_index_is_rejected(tn):
         tn.nfft_adjoint(x, pos, torch.tensor([-1, 0, 0, 1], device="cuda"), bandwidth=8, cutoff=2)
 
 
+def test_batch_vector_ends_are_remembered_and_follow_in_place_updates(tn):
+    """B = batch[-1] + 1 costs a blocking read-back per operator call; the ends of a batch vector are remembered by tensor
+    identity + version counter (core.cpp: batch_ends).  An in-place edit through the tensor must be seen, the cache
+    switches of the plan cache clear / disable it, and a vector that turns invalid is rejected."""
+    from torch_nfft_amd import ops
+    rng = np.random.default_rng(17)
+    n, N, m = 600, 16, 3
+    pos = dev((rng.random((n, 2)) - 0.5).astype(np.float32))
+    x = dev(rng.standard_normal(n).astype(np.float32))
+    batch = dev((np.arange(n) >= n // 2).astype(np.int64))          # two point sets
+    ops.plan_cache_clear()
+    assert tn.nfft_adjoint(x, pos, batch, bandwidth=N, cutoff=m).shape[0] == 2
+    assert tn.nfft_adjoint(x, pos, batch, bandwidth=N, cutoff=m).shape[0] == 2   # (from the remembered ends)
+    batch[n - 10:] = 2                                               # in place: version counter changes
+    y3 = tn.nfft_adjoint(x, pos, batch, bandwidth=N, cutoff=m)
+    assert y3.shape[0] == 3
+    ref = nfft_ref.nfft_adjoint(host(x), host(pos), host(batch), N=N, m=m)
+    assert rel_l2(host(y3), ref) < T1
+    ops.plan_cache_enabled(False)
+    assert tn.nfft_adjoint(x, pos, batch, bandwidth=N, cutoff=m).shape[0] == 3
+    ops.plan_cache_enabled(True)
+    batch[0] = -1
+    with pytest.raises(RuntimeError, match="Input mismatch"):
+        tn.nfft_adjoint(x, pos, batch, bandwidth=N, cutoff=m)
+    with pytest.raises(RuntimeError, match="Input mismatch"):       # (remembered ends are checked like fresh ones)
+        tn.nfft_adjoint(x, pos, batch, bandwidth=N, cutoff=m)
+    ops.plan_cache_clear()
+
+
 def test_plan_cache_across_streams(tn):
     """A plan built on one stream and consumed on another: the consumer waits for the build and the results agree."""
     from torch_nfft_amd import ops

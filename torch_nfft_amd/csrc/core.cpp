@@ -45,8 +45,65 @@ struct Points {
     at::Tensor pos, batch;  // contiguous; batch undefined when the caller passed None
 };
 
+// ---- ends of the batch vector -------------------------------------------------------------------------------
+// B = batch[-1] + 1 needs a blocking read-back (as in the reference, core_cuda.cu:60): ~35 us per operator call -- more
+// than a small transform takes, and paid again by the forward transform, the backward pass and the next step on the very
+// same vector.  The two ends of the last few batch vectors are remembered by tensor identity + version counter: the same
+// rules, the same limitation (writes that bypass the version counter) and the same switches as the point-plan cache
+// below (ops.plan_cache_enabled / plan_cache_clear).  Inference tensors carry no version counter: always read back.
+struct BatchEnds {
+    const void *ptr = nullptr;
+    int64_t version = -1, n = -1, first = 0, last = 0;
+    int device = -1;
+    at::Tensor keep;  // keeps the address from being recycled
+    uint64_t last_use = 0;
+};
+struct BatchEndsCache {
+    std::mutex mutex;
+    BatchEnds entries[4];
+    bool enabled = true;
+    uint64_t tick = 0;
+    void clear() { for (BatchEnds &e : entries) e = BatchEnds(); }
+};
+BatchEndsCache &g_ends = *new BatchEndsCache;  // (never destroyed: see the plan cache)
+
+void batch_ends(const at::Tensor &batch, int64_t n, int64_t &first, int64_t &last)
+{
+    const bool cacheable = !batch.is_inference();
+    const void *ptr = batch.data_ptr();
+    const int device = batch.device().index();
+    int64_t version = -1;
+    if (cacheable) {
+        std::lock_guard<std::mutex> lock(g_ends.mutex);
+        if (g_ends.enabled) {
+            version = (int64_t)batch._version();
+            for (BatchEnds &e : g_ends.entries) {
+                if (e.ptr == ptr && e.version == version && e.n == n && e.device == device) {
+                    e.last_use = ++g_ends.tick;
+                    first = e.first;
+                    last = e.last;
+                    return;
+                }
+            }
+        }
+    }
+    const at::Tensor ends = at::stack({batch[0], batch[n - 1]}).cpu();
+    first = ends[0].item<int64_t>();
+    last = ends[1].item<int64_t>();
+    if (cacheable && version >= 0) {
+        std::lock_guard<std::mutex> lock(g_ends.mutex);
+        if (!g_ends.enabled) return;
+        BatchEnds *slot = &g_ends.entries[0];
+        for (BatchEnds &e : g_ends.entries)
+            if (e.last_use < slot->last_use) slot = &e;
+        slot->ptr = ptr; slot->version = version; slot->n = n; slot->device = device;
+        slot->first = first; slot->last = last; slot->keep = batch; slot->last_use = ++g_ends.tick;
+    }
+}
+
 // check_point_input (core_cuda.cu:38-66).  One blocking read-back, as in the reference (:60) -- it also fetches
-// batch[0], so that a negative first entry of the (sorted) batch vector is rejected instead of being clamped.
+// batch[0], so that a negative first entry of the (sorted) batch vector is rejected instead of being clamped -- unless
+// the ends of this very vector are remembered (batch_ends above).
 Points check_points(const at::Tensor &pos, const c10::optional<at::Tensor> &opt_batch, const char *batch_name)
 {
     TORCH_CHECK(pos.is_cuda(), "pos must be CUDA tensor");
@@ -67,8 +124,8 @@ Points check_points(const at::Tensor &pos, const c10::optional<at::Tensor> &opt_
         CHECK_INPUT(batch.device() == pos.device());
         p.batch = batch.contiguous();
         if (p.n > 0) {
-            const at::Tensor ends = at::stack({p.batch[0], p.batch[p.n - 1]}).cpu();
-            const int64_t first = ends[0].item<int64_t>(), last = ends[1].item<int64_t>();
+            int64_t first = 0, last = 0;
+            batch_ends(p.batch, p.n, first, last);
             CHECK_INPUT(first >= 0 && last >= first);
             p.B = last + 1;
         }
@@ -236,6 +293,11 @@ at::Tensor get_plan(const Points &p, const nfft_hip_problem &q)
 int64_t plan_cache_control(int64_t action)
 {
     std::lock_guard<std::mutex> lock(g_cache.mutex);
+    if (action >= 0 && action <= 2) {  // the remembered batch-vector ends follow the same switches
+        std::lock_guard<std::mutex> lock2(g_ends.mutex);
+        g_ends.clear();
+        if (action != 0) g_ends.enabled = action == 1;
+    }
     switch (action) {
     case 0: g_cache.clear(); return 0;
     case 1: g_cache.enabled = true; return 0;

@@ -13,7 +13,9 @@ adjoint, fastsum) reuse it instead of re-binning.  The cache lives in ``core.so`
 identity + version counter, stream-aware (a plan built on one stream is waited for and recorded on the consuming
 stream).  LIMITATION: writes that bypass the version counter -- ``pos.data.copy_()``, kernels of other libraries,
 DLPack aliases -- are invisible to it; code that edits points that way calls ``plan_cache_clear()`` afterwards or
-``plan_cache_enabled(False)`` once.
+``plan_cache_enabled(False)`` once.  The same switches govern the remembered ENDS of the batch vector
+(``B = batch[-1] + 1`` otherwise costs a blocking read-back of ~35 us in every operator call, as in the reference's
+``check_point_input``, core_cuda.cu:60): same key (identity + version counter), same limitation.
 """
 import torch
 
