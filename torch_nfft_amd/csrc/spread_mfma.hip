@@ -53,8 +53,20 @@ __device__ unsigned long long *g_spread_trace = nullptr;
         if (!OVERFLOW && threadIdx.x == 0 && g_spread_trace)                                                      \
             g_spread_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = (value);                 \
     } while (0)
+// Step-level stamps (shader clock, s_memtime) of the first kStepTraceWgs workgroups: per wave and pipeline step the time
+// at the loop top, after the accumulation, after the operand build and after the barrier (scripts/spread_steps.py).
+constexpr int kStepTraceWgs = 16, kStepTraceSteps = 64;
+__device__ unsigned long long *g_step_trace = nullptr;
+#define NFFT_STEP(i, point)                                                                                       \
+    do {                                                                                                          \
+        if (!OVERFLOW && g_step_trace && blockIdx.y == 0 && blockIdx.x < kStepTraceWgs && (i) >= 0 &&            \
+            (i) < kStepTraceSteps && lane == 0)                                                                   \
+            g_step_trace[((((size_t)blockIdx.x * 16 + wave) * kStepTraceSteps + (i)) * 4) + (point)] =            \
+                __builtin_amdgcn_s_memtime();                                                                     \
+    } while (0)
 #else
 #define NFFT_TRACE(slot, value) do { } while (0)
+#define NFFT_STEP(i, point) do { } while (0)
 #endif
 
 namespace {
@@ -421,85 +433,72 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
         while (true) {
             // all 64 lanes add 1 (the compiler folds this into one ds_add of 64 per wave): the counter runs in units of
             // 64, lane 0 sees the wave's base value
-            const int t = __builtin_amdgcn_readfirstlane(atomicAdd(counter, 1)) >> 6;
-            if (t >= 3 * nkb) break;
-            const int j = t / 3, kind = t - 3 * j;
-            if (kind == 0) {
-                // B fragments [column tile][hi/lo][lane = 32 (k / 8) + column] element k % 8, f16 hi / lo of psi2
+            const int j = __builtin_amdgcn_readfirstlane(atomicAdd(counter, 1)) >> 6;
+            if (j >= nkb) break;
+            // One task = the three operand tables of K-block j.  A task is a chain of LDS round trips (counter, inputs,
+            // zero fill, scattered writes), not arithmetic: as three tasks of one table each the builds took 57 % of the
+            // workgroup's wave time (profiles/r03_experiments.md); in one task their chains overlap and the point's
+            // inputs are read once.
+            // ---- zero fills: B fragments [column tile][hi/lo][lane = 32 (k / 8) + column] element k % 8, psi1 [row][point]
+            {
                 const f16x8 zero = (_Float16)0.0f;
                 O.bfrag[j][0][0][lane] = zero;
                 O.bfrag[j][0][1][lane] = zero;
                 O.bfrag[j][1][0][lane] = zero;
                 O.bfrag[j][1][1][lane] = zero;
-                asm volatile("" ::: "memory");  // the 16-bit scatter below must stay behind the zero fill
-                // lane = 4 k + g: point k of the K-block, taps g, g + 4, g + 8 (, g + 12) -- the point's cell and fraction
-                // are read once, the tap loop has a compile-time trip count and no division
-                int touched = 0;
-                {
-                    const int k = lane >> 2, g4 = lane & 3;
-                    const int slot = j * kKB + k;
-                    const int c2v = S.c2[slot];
-                    const float f2v = S.f2[slot];
-                    _Float16 *const base_h = (_Float16 *)&O.bfrag[j][0][0][32 * (k >> 3)] + (k & 7);
-#pragma unroll
-                    for (int t = 0; t < (W + 3) / 4; ++t) {
-                        const int l = g4 + 4 * t;
-                        const int col = c2v - m + l;
-                        const float d = f2v + (float)(m - l);
-                        const float v = __builtin_amdgcn_exp2f(sc * d * d) * kOpScale;
-                        unsigned hi, lo;
-                        split_pair(v, 0.0f, hi, lo);
-                        if (l < W && (unsigned)col < 64u) {  // (padding slots fail the second test)
-                            // element [col >> 5][hi/lo][32 (k >> 3) + (col & 31)][k & 7] of bfrag[j]
-                            _Float16 *ph = base_h + (col >> 5) * (2 * 64 * 8) + (col & 31) * 8;
-                            ph[0] = __builtin_bit_cast(_Float16, (unsigned short)hi);
-                            ph[64 * 8] = __builtin_bit_cast(_Float16, (unsigned short)lo);
-                            touched |= 1 + (col >> 5);
-                        }
-                    }
-                }
-                // the plan orders a slab's points by column group (common.h): most K-blocks touch one tile only
-                const int t0 = __builtin_amdgcn_ballot_w64((touched & 1) != 0) != 0ull;
-                const int t1 = __builtin_amdgcn_ballot_w64((touched & 2) != 0) != 0ull;
-                if (lane == 0) O.halves[j] = t0 + 2 * t1;
-            } else if (kind == 1) {
-                // psi1 table [row][point]
                 f32x4 *pz = (f32x4 *)&O.psi1[j][0][0];
-                const f32x4 zero = 0.0f;
-                for (int e = lane; e < 32 * kPsiStride / 4; e += 64) pz[e] = zero;
-                asm volatile("" ::: "memory");
-                {
-                    const int k = lane >> 2, g4 = lane & 3;  // as above
-                    const int slot = j * kKB + k;
-                    const int c1v = S.c1[slot];
-                    const float f1v = S.f1[slot];
+                const f32x4 zero4 = 0.0f;
+                for (int e = lane; e < 32 * kPsiStride / 4; e += 64) pz[e] = zero4;
+            }
+            asm volatile("" ::: "memory");  // the scattered writes below must stay behind the zero fills
+            // lane = 4 k + g: point k of the K-block, taps g, g + 4, g + 8 (, g + 12) -- the point's cell and fraction
+            // are read once, the tap loops have a compile-time trip count and no division
+            const int k = lane >> 2, g4 = lane & 3;
+            const int slot = j * kKB + k;
+            const int c2v = S.c2[slot], c1v = S.c1[slot];
+            const float f2v = S.f2[slot], f1v = S.f1[slot], f0v = S.f0[slot], xv = S.x[slot];
+            const int sl = S.slab[j];
+            int touched = 0;
+            _Float16 *const base_h = (_Float16 *)&O.bfrag[j][0][0][32 * (k >> 3)] + (k & 7);
 #pragma unroll
-                    for (int t = 0; t < (W + 3) / 4; ++t) {
-                        const int l = g4 + 4 * t;
-                        const int row = c1v - m + l;
-                        const float d = f1v + (float)(m - l);
-                        const float v = __builtin_amdgcn_exp2f(sc * d * d);
-                        if (l < W && (unsigned)row < 32u) O.psi1[j][row][k] = v;
+            for (int t = 0; t < (W + 3) / 4; ++t) {
+                const int l = g4 + 4 * t;
+                // B fragments: f16 hi / lo of psi2 (times the operand scale)
+                {
+                    const int col = c2v - m + l;
+                    const float d = f2v + (float)(m - l);
+                    const float v = __builtin_amdgcn_exp2f(sc * d * d) * kOpScale;
+                    unsigned hi, lo;
+                    split_pair(v, 0.0f, hi, lo);
+                    if (l < W && (unsigned)col < 64u) {  // (padding slots fail the second test)
+                        // element [col >> 5][hi/lo][32 (k >> 3) + (col & 31)][k & 7] of bfrag[j]
+                        _Float16 *ph = base_h + (col >> 5) * (2 * 64 * 8) + (col & 31) * 8;
+                        ph[0] = __builtin_bit_cast(_Float16, (unsigned short)hi);
+                        ph[64 * 8] = __builtin_bit_cast(_Float16, (unsigned short)lo);
+                        touched |= 1 + (col >> 5);
                     }
                 }
-            } else {
-                // axis-0 table [tap][point]: x' psi0 (the same lane = 4 k + g mapping)
+                // psi1 table [row][point]
                 {
-                    const int k = lane >> 2, g4 = lane & 3;
-                    const int slot = j * kKB + k;
-                    const float f0v = S.f0[slot], xv = S.x[slot];
-                    const int sl = S.slab[j];
-#pragma unroll
-                    for (int t = 0; t < (W + 3) / 4; ++t) {
-                        const int l0 = g4 + 4 * t;
-                        const float d = f0v + (float)(m - l0);
-                        // odd planes accumulate the negated sum (undone at the flush): the sign-independent part of the
-                        // MFMA accumulation's truncation bias then alternates from plane to plane
-                        const float sgn = ((sl + l0) & 1) ? -kOpScale : kOpScale;
-                        if (l0 < W) O.atab[j][l0][k] = xv * __builtin_amdgcn_exp2f(sc * d * d) * sgn;
-                    }
+                    const int row = c1v - m + l;
+                    const float d = f1v + (float)(m - l);
+                    const float v = __builtin_amdgcn_exp2f(sc * d * d);
+                    if (l < W && (unsigned)row < 32u) O.psi1[j][row][k] = v;
                 }
-                if (lane == 0) O.slab[j] = S.slab[j];
+                // axis-0 table [tap][point]: x' psi0.  Odd planes accumulate the negated sum (undone at the flush): the
+                // sign-independent part of the MFMA accumulation's truncation bias then alternates from plane to plane
+                {
+                    const float d = f0v + (float)(m - l);
+                    const float sgn = ((sl + l) & 1) ? -kOpScale : kOpScale;
+                    if (l < W) O.atab[j][l][k] = xv * __builtin_amdgcn_exp2f(sc * d * d) * sgn;
+                }
+            }
+            // the plan orders a slab's points by column group (common.h): most K-blocks touch one tile only
+            const int t0 = __builtin_amdgcn_ballot_w64((touched & 1) != 0) != 0ull;
+            const int t1 = __builtin_amdgcn_ballot_w64((touched & 2) != 0) != 0ull;
+            if (lane == 0) {
+                O.halves[j] = t0 + 2 * t1;
+                O.slab[j] = sl;
             }
         }
     };
@@ -580,6 +579,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     NFFT_TRACE(2, __builtin_amdgcn_s_memrealtime());
     NFFT_TRACE(5, (unsigned long long)(unsigned)total | ((unsigned long long)(unsigned)(tile_offsets[bin0 + wrap(s_lo + nslab - 1, g.M) + 1] - tile_offsets[bin0 + wrap(s_lo, g.M)]) << 32));
     for (int i = -1; i < nbatch; ++i) {
+        NFFT_STEP(i, 0);
         if (stager) {
             if (i + 2 < nbatch) stage_convert(L.stag[i & 1], i + 2, true);
             request_coefficients(i + 4);
@@ -587,10 +587,13 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
         }
         if (tid == 0) L.task_counter[i & 1] = 0;  // for the next step; its last user is behind the previous barrier
         if (i >= 0 && owner) accumulate(L.ops[i & 1], min(kNKB, total - i * kNKB));
+        NFFT_STEP(i, 1);
         if (i + 1 < nbatch)
             build_tasks(L.stag[(i + 1) & 1], L.ops[(i + 1) & 1], min(kNKB, total - (i + 1) * kNKB),
                         &L.task_counter[(i + 1) & 1]);
+        NFFT_STEP(i, 2);
         barrier_lds_only();
+        NFFT_STEP(i, 3);
     }
     // the dummy requests of the last steps must have landed before the workgroup gives its LDS back
     if (stager) wait_lds_dma();
@@ -612,6 +615,10 @@ bool spread_mfma_supported(const Geom &g) { return g.dim == 3 && g.wide; }
 extern "C" int nfft_dbg_set_spread_trace(void *device_buffer)
 {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_spread_trace), &device_buffer, sizeof(device_buffer));
+}
+extern "C" int nfft_dbg_set_step_trace(void *device_buffer)  // 16 workgroups x 16 waves x 64 steps x 4 stamps x 8 bytes
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_step_trace), &device_buffer, sizeof(device_buffer));
 }
 #endif
 
