@@ -178,12 +178,18 @@ __device__ __forceinline__ void load_point(const float *__restrict__ pos, int di
 // several global loads in flight instead of one load -> atomic (-> store) chain per point.
 constexpr int kSortUnroll = 8;
 
+template <bool COMMON>
 __global__ void __launch_bounds__(kSortThreads)
-sort1_count_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restrict__ batch, int64_t n, int64_t B,
+sort1_count_kernel(Geom g_in, const float *__restrict__ pos, const int64_t *__restrict__ batch, int64_t n, int64_t B,
                    int npencils, int nblocks, int block_points, int *__restrict__ hist /* [pencil][block] */,
                    unsigned short *__restrict__ key1 /* first-level bin of every point (not for the owned tiling) */,
                    int *__restrict__ status)
 {
+    // COMMON: a 3-D problem on the scatter tiling (every benchmark configuration): with the two flags constant the
+    // per-point paths lose their run-time branches on dimension and tiling (8-fold unrolled: 43 KB of code per kernel
+    // before), the instruction-bound count passes most of all
+    Geom g = g_in;
+    if constexpr (COMMON) { g.dim = 3; g.owned = 0; }
     extern __shared__ int lds_hist[];
     for (int i = threadIdx.x; i < npencils; i += kSortThreads) lds_hist[i] = 0;
     __syncthreads();
@@ -216,11 +222,17 @@ sort1_count_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restr
     for (int i = threadIdx.x; i < npencils; i += kSortThreads) hist[(int64_t)i * nblocks + blockIdx.x] = lds_hist[i];
 }
 
+template <bool COMMON>
 __global__ void __launch_bounds__(kSortThreads)
-sort1_scatter_kernel(Geom g, const float *__restrict__ pos, const int64_t *__restrict__ batch, int64_t n, int64_t B,
+sort1_scatter_kernel(Geom g_in, const float *__restrict__ pos, const int64_t *__restrict__ batch, int64_t n, int64_t B,
                      int npencils, int nblocks, int block_points, const int *__restrict__ hscan, const unsigned short *__restrict__ key1,
                      float4 *__restrict__ tmp)
 {
+    // COMMON: a 3-D problem on the scatter tiling (every benchmark configuration): with the two flags constant the
+    // per-point paths lose their run-time branches on dimension and tiling (8-fold unrolled: 43 KB of code per kernel
+    // before), the instruction-bound count passes most of all
+    Geom g = g_in;
+    if constexpr (COMMON) { g.dim = 3; g.owned = 0; }
     extern __shared__ int lds_cur[];
     for (int i = threadIdx.x; i < npencils; i += kSortThreads) lds_cur[i] = hscan[(int64_t)i * nblocks + blockIdx.x];
     __syncthreads();
@@ -295,10 +307,16 @@ __device__ __forceinline__ void sort2_range(const int *__restrict__ hscan, int l
     r1 = p0 + (int)(len * (part + 1) / kSort2Parts);
 }
 
+template <bool COMMON>
 __global__ void __launch_bounds__(kSortThreads)
-sort2_count_kernel(Geom g, int nblocks, const int *__restrict__ hscan, const float4 *__restrict__ tmp,
+sort2_count_kernel(Geom g_in, int nblocks, const int *__restrict__ hscan, const float4 *__restrict__ tmp,
                    int *__restrict__ hist2 /* [l1][part][key] */, unsigned short *__restrict__ key2 /* fine key of every record */)
 {
+    // COMMON: a 3-D problem on the scatter tiling (every benchmark configuration): with the two flags constant the
+    // per-point paths lose their run-time branches on dimension and tiling (8-fold unrolled: 43 KB of code per kernel
+    // before), the instruction-bound count passes most of all
+    Geom g = g_in;
+    if constexpr (COMMON) { g.dim = 3; g.owned = 0; }
     extern __shared__ int lds2[];
     const int l1 = blockIdx.x, part = blockIdx.y;
     const int pencil = l1 / g.l1seg, sg = l1 - pencil * g.l1seg;
@@ -639,17 +657,18 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
         const int64_t items = L.npencils * L.nblocks + 1;
         const size_t lds1 = (size_t)npencils * 4;
         unsigned short *key1 = (unsigned short *)(base + L.off_key1), *key2 = (unsigned short *)(base + L.off_key2);
-        hipLaunchKernelGGL(sort1_count_kernel, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
+        const bool common = g.dim == 3 && !g.owned;
+        hipLaunchKernelGGL(common ? sort1_count_kernel<true> : sort1_count_kernel<false>, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
                            npencils, nblocks, (int)L.block_points, hist, key1, device_status_block());
         size_t scan_bytes = 0;
         NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, hist, hscan, (int)items, stream));
         if ((int64_t)scan_bytes > L.scan_bytes) { set_error("scan scratch too small"); return 2; }
         NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(base + L.off_scan, scan_bytes, hist, hscan, (int)items, stream));
-        hipLaunchKernelGGL(sort1_scatter_kernel, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
+        hipLaunchKernelGGL(common ? sort1_scatter_kernel<true> : sort1_scatter_kernel<false>, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
                            npencils, nblocks, (int)L.block_points, hscan, key1, tmp);
         int *hist2 = (int *)(base + L.off_hist2);
         const size_t lds2 = (size_t)g.l1bins * g.SB * g.CG * 4;
-        hipLaunchKernelGGL(sort2_count_kernel, dim3(npencils, kSort2Parts), dim3(kSortThreads), lds2, stream, g, nblocks,
+        hipLaunchKernelGGL(common ? sort2_count_kernel<true> : sort2_count_kernel<false>, dim3(npencils, kSort2Parts), dim3(kSortThreads), lds2, stream, g, nblocks,
                            hscan, tmp, hist2, key2);
         hipLaunchKernelGGL(sort2_scatter_kernel, dim3(npencils, kSort2Parts), dim3(kSortThreads), 2 * lds2, stream, g,
                            npencils, nblocks, hscan, tmp, hist2, key2, offsets, (int *)(base + L.off_groups), perm, spos);
