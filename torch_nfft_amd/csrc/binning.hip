@@ -13,8 +13,9 @@
 
 namespace nfft {
 
-constexpr int kSortBlockPoints = 16384; // most points per workgroup in the first-level passes (long runs per bin: the
-                                        // scatter writes 16-byte records, ~18 per (workgroup, bin) at C3)
+constexpr int kSortBlockPoints = 8192;  // most points per workgroup in the first-level passes: runs of ~6 16-byte records
+                                        // per (workgroup, bin) at C3.  Measured at the end of round 3 (lean kernels, plan stage
+                                        // at C3): 4 096: 0.368, 8 192: 0.334, 16 384: 0.367, 32 768: 0.386 ms
 constexpr int kSortThreads = 512;
 constexpr int kMaxPencilsLds = 8192;    // first-level bins that fit an LDS histogram
 constexpr int kSort2Parts = 8;          // workgroups that share one first-level bin in the second level (a dense bin of a
