@@ -484,11 +484,13 @@ print("RESULT", tuple(y.shape), bool(torch.isfinite(y.abs()).all()))
 
 
 @pytest.mark.parametrize("env_extra", [{"NFFT_HIP_SPREAD": "lds"},
-                                       {"NFFT_HIP_GATHER": "lds", "NFFT_HIP_ROCFFT_ROWS": "1"}])
+                                       {"NFFT_HIP_GATHER": "lds", "NFFT_HIP_ROCFFT_ROWS": "1"},
+                                       {"NFFT_HIP_COL_XCD": "0"}])
 def test_fallback_kernels_match_oracle(env_extra):
     """The kernels the defaults replaced stay selectable and correct: NFFT_HIP_SPREAD=lds (f64-LDS-atomic spreading,
-    narrow pencil tiling), NFFT_HIP_GATHER=lds (lane-per-point interpolation on the wide tiling) and
-    NFFT_HIP_ROCFFT_ROWS=1 (rocFFT instead of the own row passes) on a 128^3 grid: adjoint and forward vs the oracle."""
+    narrow pencil tiling), NFFT_HIP_GATHER=lds (lane-per-point interpolation on the wide tiling),
+    NFFT_HIP_ROCFFT_ROWS=1 (rocFFT instead of the own row passes) and NFFT_HIP_COL_XCD=0 (column passes in plain
+    workgroup order) on a 128^3 grid: adjoint and forward vs the oracle."""
     import subprocess
     import sys
     code = r'''
