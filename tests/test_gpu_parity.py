@@ -113,7 +113,10 @@ def _random_problem(rng, d, n, B, cols, complex_x):
 @pytest.mark.parametrize("d,N,m", [(1, 64, 2), (1, 32, 3), (1, 512, 4), (2, 16, 3), (2, 32, 4), (2, 64, 2),
                                    (3, 16, 4), (3, 16, 2), (3, 24, 3), (3, 32, 4), (2, 16, 6), (3, 16, 5),
                                    (1, 64, 8), (2, 32, 8), (3, 20, 7), (2, 8, 1),
-                                   (1, 48, 3), (1, 100, 4), (1, 4096, 2)])  # (1-D outside the fused path: smallgrid.hip)
+                                   (1, 48, 3), (1, 100, 4), (1, 4096, 2),  # (1-D outside the fused path: smallgrid.hip)
+                                   # large grids that are not a power of two: the cell / fraction split of a coordinate
+                                   # must stay exact there (a contracted multiply once cost 6e-9 M in relative error)
+                                   (1, 1000, 4), (1, 3000, 8), (2, 100, 4), (3, 40, 3)])
 @pytest.mark.parametrize("complex_x", [False, True])
 def test_adjoint_and_forward_vs_oracle(tn, d, N, m, complex_x):
     rng = np.random.default_rng(1000 * d + N + m)

@@ -209,7 +209,14 @@ __device__ __forceinline__ float win_norm(int m) { return sqrtf(0.75f / (float)m
 __device__ __forceinline__ void split_cell(float pos, int M, int &cell, float &frac)
 {
     const float Mf = (float)M;
-    const float hi = pos * Mf;
+    // The rounded product, through an asm statement so that nothing can be fused into it.  Under -ffp-contract=fast the
+    // compiler turned `hi - fl` below into fma(pos, M, -fl) -- the EXACT product again -- and adding the residual `lo`
+    // counted it twice: a position error of half an ulp of pos * M, i.e. a relative error of ~6e-9 M in the transform
+    // for grids that are not a power of two (1.2e-5 at M = 2000; found by scripts/fuzz_more.py).  Neither HIP's
+    // __fmul_rn (a plain product) nor `#pragma clang fp contract(off)` kept the backend from fusing.  Power-of-two grids
+    // take the exact fast path and never saw it.
+    float hi;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(hi) : "v"(pos), "v"(Mf));
     // Power-of-two M (every benchmark configuration) and an ordinary coordinate: pos * M is exact, so floor, fraction
     // and the periodic wrap are one instruction each -- the same (cell, frac) as the general path below in 7 instead of
     // ~25 vector instructions (three of these per point in the sort passes, in the spreading kernel's staging and in
