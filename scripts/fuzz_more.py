@@ -1,5 +1,5 @@
 """Developer tool: more seeded random configurations than tests/test_gpu_fuzz.py holds (same generator, seeds 5000 ...),
-against the oracle.  usage: python scripts/fuzz_more.py <cases>   (stops after 7 minutes)"""
+against the oracle.  usage: python scripts/fuzz_more.py <cases> [first seed, default 5000]   (stops after 7 minutes)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import numpy as np, torch
@@ -13,7 +13,8 @@ exec(compile(src, 'fz', 'exec'), ns)
 draw_case, rel = ns['draw_case'], ns['rel_l2']
 dev = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
 bad = 0; worst = 0.0; t0 = time.time()
-for seed in range(5000, 5000 + int(sys.argv[1])):
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
+for seed in range(first, first + int(sys.argv[1])):
     c = draw_case(seed)
     pos, batch = dev(c["pos"]), dev(c["batch"])
     ya = tn.nfft_adjoint(dev(c["x"]), pos, batch, bandwidth=c["N"], cutoff=c["m"], real_output=c["real_adj"])
@@ -27,4 +28,4 @@ for seed in range(5000, 5000 + int(sys.argv[1])):
         print("FAIL seed", seed, "d=%d N=%d m=%d B=%d n=%d cols=%s" % (c["d"], c["N"], c["m"], c["B"], c["n"], c["cols"]), ea, ef, flush=True)
     if time.time() - t0 > 420: print("time limit at seed", seed); break
 ops.check_status()
-print("cases", seed - 5000 + 1, "failures", bad, "worst", worst)
+print("cases", seed - first + 1, "failures", bad, "worst", worst)
