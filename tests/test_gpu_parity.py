@@ -116,7 +116,7 @@ def _random_problem(rng, d, n, B, cols, complex_x):
                                    (1, 48, 3), (1, 100, 4), (1, 4096, 2),  # (1-D outside the fused path: smallgrid.hip)
                                    # large grids that are not a power of two: the cell / fraction split of a coordinate
                                    # must stay exact there (a contracted multiply once cost 6e-9 M in relative error)
-                                   (1, 1000, 4), (1, 3000, 8), (2, 100, 4), (3, 40, 3)])
+                                   (1, 1000, 4), (1, 3000, 8), (2, 100, 4), (3, 40, 3), (3, 48, 4)])  # (96^3: matrix cores)
 @pytest.mark.parametrize("complex_x", [False, True])
 def test_adjoint_and_forward_vs_oracle(tn, d, N, m, complex_x):
     rng = np.random.default_rng(1000 * d + N + m)
