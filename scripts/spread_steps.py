@@ -27,17 +27,23 @@ torch.cuda.synchronize()
 trace.zero_()
 _lib.check(lib.nfft_hip_spread(ctypes.byref(prob), p(plan), p(x), 1, p(grid), p(scratch), s))
 torch.cuda.synchronize()
-t = trace.cpu().numpy().astype(np.float64)
+raw = trace.cpu().numpy()
+ntask = (raw[..., 2] >> 56).astype(np.float64)  # build tasks the wave took in the step (packed into the stamp's top byte)
+raw[..., 2] &= (1 << 56) - 1
+t = raw.astype(np.float64)
 ok = (t[..., 0] > 0) & (t[..., 3] > 0)
 ok[:, :, :3] = False  # (pipeline fill)
-roles = {"owners (waves 0-11)": range(0, 12), "stagers (waves 12, 13)": (12, 13), "builders (waves 14, 15)": (14, 15)}
+NOWN = int(os.environ.get("NOWN", 12))  # plane-owner waves of the build under test
+roles = {"owners (waves 0-%d)" % (NOWN - 1): range(0, NOWN), "stagers (waves %d, %d)" % (NOWN, NOWN + 1): (NOWN, NOWN + 1),
+         "builders (waves %d-15)" % (NOWN + 2): range(NOWN + 2, 16)}
 print("s_memtime ticks (100 MHz on gfx950 -> 10 ns each); steps 3..63 of the first 16 workgroups")
 step = (t[..., 3] - t[..., 0])
 print("step (top -> after barrier), all waves: mean %.0f ticks" % step[ok].mean())
 for name, waves in roles.items():
     sel = np.zeros_like(ok); sel[:, list(waves)] = True; sel &= ok
     a = (t[..., 1] - t[..., 0])[sel].mean(); b = (t[..., 2] - t[..., 1])[sel].mean(); c = (t[..., 3] - t[..., 2])[sel].mean()
-    print("%-26s staging/accumulate %.0f   build %.0f   wait at the barrier %.0f" % (name, a, b, c))
+    print("%-26s staging/accumulate %.0f   build %.0f (%.2f tasks per step and wave)   wait at the barrier %.0f"
+          % (name, a, b, ntask[sel].mean(), c))
 # the wave that arrives last at the barrier, per step
 arrive = t[..., 2]
 last = np.argmax(np.where(ok, arrive, 0), axis=1)  # [wg, step]

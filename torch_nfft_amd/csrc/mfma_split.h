@@ -24,8 +24,7 @@ constexpr float kOpScale = 2048.0f;
 // v_fma_mixlo/mixhi_f16 -- an FMA with an f16 HALF-register result -- cost 8.5-8.9 (13 with one wave: the partial
 // register write chains them), v_fma_mix_f32 4.6, v_cvt_pk_f16_f32 4.5, v_pk_mul_f32 4.7, v_mul_f32 3.1.  So the f16
 // results are formed by the packed convert and only full-register FMAs are used: 4 instructions (18 cycles) instead of
-// 3 (21.5), and for products 5 (23) instead of 4 (35) -- the products are 10 x 16 instructions per K-block of the
-// spreading kernel.  Separate asm statements: the compiler interleaves the chains of neighbouring pairs.
+// 3 (21.5).  Separate asm statements: the compiler interleaves the chains of neighbouring pairs.
 __device__ __forceinline__ void split_pair(const float v0, const float v1, unsigned &hi, unsigned &lo)
 {
     float r0, r1;
@@ -35,18 +34,41 @@ __device__ __forceinline__ void split_pair(const float v0, const float v1, unsig
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(r0), "v"(r1));
 }
 
-// The same for products p * a: hi = RN16(RN32(p a)), lo = RN16(p a - hi) with the residual taken from the EXACT product
-// (one FMA), so hi + lo carries p a to ~2^-22 whichever way hi was rounded.
-__device__ __forceinline__ void split_product_pair(const float p0, const float a0, const float p1, const float a1,
-                                                   unsigned &hi, unsigned &lo)
+// Split of a PRODUCT p a from the f16 splits of its factors (p = ph + pl, a = ah + al, all four normal f16 numbers), in
+// packed f16 arithmetic: hi = RN16(ph ah); e = ph ah - hi EXACTLY (the rounding error of an f16 product is an f16 number:
+// one FMA); lo = RN16(pl ah + RN16(ph al + e)).  hi + lo = p a (1 + O(2^-21)): the dropped term pl al is 2^-22 of the
+// product and the two roundings of lo are 2^-11 of a 2^-10 part.  4 VOP3P instructions per PAIR of elements and no fp32
+// operand: the spreading kernel's plane-owner waves form 8 such pairs per K-block and plane, which was 6 instructions per
+// pair (v_mul x2, v_cvt_pk, v_fma_mix x2, v_cvt_pk) on fp32 factors (scripts/ubench/phase_interleave.hip: three owner waves
+// per SIMD, 16 packed instead of 24 mixed instructions beside 3 MFMAs, -9.5 % time).  Written in asm: under
+// -ffp-contract=fast nothing may re-associate an error-free transformation (tests/test_gpu_eft.py checks it bit for bit).
+// (four pairs per statement: the compiler pads every boundary between dependent asm statements with an s_nop, and one
+// statement lets the four independent chains alternate)
+__device__ __forceinline__ void split_product_f16x4(const u32x4 ph, const u32x4 pl, const u32x4 ah, const u32x4 al, u32x4 &hi,
+                                                    u32x4 &lo)
 {
-    float v0, v1, r0, r1;
-    asm("v_mul_f32 %0, %1, %2" : "=v"(v0) : "v"(p0), "v"(a0));
-    asm("v_mul_f32 %0, %1, %2" : "=v"(v1) : "v"(p1), "v"(a1));
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
-    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(p0), "v"(a0), "v"(hi));
-    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(p1), "v"(a1), "v"(hi));
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(r0), "v"(r1));
+    unsigned h0, h1, h2, h3, q0, q1, q2, q3;
+    asm("v_pk_mul_f16 %0, %8, %16\n\t"
+        "v_pk_mul_f16 %1, %9, %17\n\t"
+        "v_pk_mul_f16 %2, %10, %18\n\t"
+        "v_pk_mul_f16 %3, %11, %19\n\t"
+        "v_pk_fma_f16 %4, %8, %16, %0 neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+        "v_pk_fma_f16 %5, %9, %17, %1 neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+        "v_pk_fma_f16 %6, %10, %18, %2 neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+        "v_pk_fma_f16 %7, %11, %19, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+        "v_pk_fma_f16 %4, %8, %20, %4\n\t"
+        "v_pk_fma_f16 %5, %9, %21, %5\n\t"
+        "v_pk_fma_f16 %6, %10, %22, %6\n\t"
+        "v_pk_fma_f16 %7, %11, %23, %7\n\t"
+        "v_pk_fma_f16 %4, %12, %16, %4\n\t"
+        "v_pk_fma_f16 %5, %13, %17, %5\n\t"
+        "v_pk_fma_f16 %6, %14, %18, %6\n\t"
+        "v_pk_fma_f16 %7, %15, %19, %7"
+        : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+        : "v"(ph.x), "v"(ph.y), "v"(ph.z), "v"(ph.w), "v"(pl.x), "v"(pl.y), "v"(pl.z), "v"(pl.w), "v"(ah.x), "v"(ah.y),
+          "v"(ah.z), "v"(ah.w), "v"(al.x), "v"(al.y), "v"(al.z), "v"(al.w));
+    hi = u32x4{h0, h1, h2, h3};
+    lo = u32x4{q0, q1, q2, q3};
 }
 
 // One dword per active lane, global -> LDS without a register in between (LDS-DMA): lane l of the wave lands at

@@ -11,18 +11,21 @@
 //     a plane is a wave-uniform row of a small table.  Inside a slab the plan orders the points by the 32-column half of
 //     the tile their window lies in (column groups, common.h): the operand build records which halves a K-block
 //     touches, and the owners skip the 3 MFMAs of an untouched half (a third of all MFMAs at config C3);
-//   * with one or two coefficient columns the kernel permutes `x` itself: the pass that finds the work item's largest
-//     |x| (the f16 operand scale) reads the caller's array through the plan's permutation, eight loads in flight per
-//     thread, and leaves the plan-ordered copy for the staging pipeline;
+//   * the coefficients are read in place: every 16-byte plan record carries the index of its point in the caller's
+//     arrays, the staging pipeline fetches x[index] by LDS-DMA two steps after the record (one or two real columns; more
+//     columns come from the plan-ordered copy of gather_rows).  The f16 operand scale is the plane's largest |x|, taken
+//     by plane_absmax_kernel in a pass of its own (no per-item prologue);
 //   * one workgroup (16 waves) sweeps a segment of a pencil.  Plane-owner wave w holds the plane z = w (mod NOWN) of
 //     the sliding window in its accumulators: no LDS accumulator, no barrier to accumulate; it flushes its 32 x 64
 //     tile with global atomics (each instruction = two 128-byte row segments) as soon as the sweep has passed it
 //     and moves on to plane z + NOWN.  NOWN = 12 for 2m+2 <= 12 -- the other four waves, one per SIMD, only stage
 //     points and build operands -- and 16 for wider windows;
-//   * per batch of 8 K-blocks the operands are built once in LDS (psi1 table, f16-split B fragments in MFMA register
-//     order, axis-0 table), one batch ahead of the MFMAs, in wave-sized tasks handed out through an LDS counter; the
-//     points themselves arrive by LDS-DMA two batches earlier.  Every owner whose plane lies in a K-block's window
-//     turns the psi1 rows into its A fragment (16 v_fma_mix) and issues 6 MFMAs.  One raw s_barrier per batch.
+//   * per batch of 8 K-blocks the operands are built once in LDS, one batch ahead of the MFMAs, in wave-sized tasks (one
+//     per K-block) handed out through an LDS counter: f16-split B fragments in MFMA register order, and the f16 splits of
+//     the psi1 table [row][point] and of the axis-0 table [tap][point] (x' psi0).  Every owner whose plane lies in a
+//     K-block's window forms the split of the PRODUCT psi1 * (x' psi0) -- its A fragment -- from the two splits with 16
+//     packed f16 instructions (mfma_split.h: split_product_f16x4; until round 4: 24 mixed fp32 / f16 instructions on fp32
+//     tables) and issues 3 MFMAs per touched column tile.  One raw s_barrier per batch.
 // Owner-computes variant (template flag OWNED, plans of the owned tiling: sparse inputs, common.h choose_owned): the
 // 32 x 64 accumulator tile is the OWNED region of the grid -- a point has a plan entry in every tile its window
 // touches (1.46x entries at m = 4) and taps that fall outside the tile are masked -- and a work item owns the planes
@@ -31,8 +34,10 @@
 // flush of the padded tiles is what the scatter variant spends its time on (1.3 TB/s chip-wide for float atomics
 // against ~6 TB/s for stores); at the density of config C3 it is not (profiles/r02_flush_variants.txt).
 // Why: ds_add_f32 is unusable on gfx950 and the f64 LDS atomic bounds spread.hip at ~3.7 ms for 1e10 taps
-// (DESIGN.md section 4); here the taps are ~0.7 TFLOP of issued matrix work per launch and the kernel runs 1.75 ms at C3,
-// bound by the sum of its vector and matrix instruction issue (the two do not overlap on a SIMD: scripts/ubench/overlap.hip).
+// (DESIGN.md section 4); here the taps are ~0.86 PFLOP of issued matrix work per launch and the kernel runs 1.34 ms at C3
+// (round 4; 93 VGPRs, no scratch).  What bounds it is not one resource: timing-only builds without the MFMAs, without the
+// packed arithmetic, without the operand loads, without the table builds or without the flush atomics each gain 3-7 %, and
+// a flag-driven variant without the per-batch barrier is slower (profiles/r04_experiments.md).
 #include <algorithm>
 #include <climits>
 #include <cstdlib>
@@ -57,16 +62,18 @@ __device__ unsigned long long *g_spread_trace = nullptr;
 // at the loop top, after the accumulation, after the operand build and after the barrier (scripts/spread_steps.py).
 constexpr int kStepTraceWgs = 16, kStepTraceSteps = 64;
 __device__ unsigned long long *g_step_trace = nullptr;
-#define NFFT_STEP(i, point)                                                                                       \
+#define NFFT_STEP_V(i, point, extra)                                                                              \
     do {                                                                                                          \
         if (!OVERFLOW && g_step_trace && blockIdx.y == 0 && blockIdx.x < kStepTraceWgs && (i) >= 0 &&            \
             (i) < kStepTraceSteps && lane == 0)                                                                   \
             g_step_trace[((((size_t)blockIdx.x * 16 + wave) * kStepTraceSteps + (i)) * 4) + (point)] =            \
-                __builtin_amdgcn_s_memtime();                                                                     \
+                __builtin_amdgcn_s_memtime() | (extra);                                                           \
     } while (0)
+#define NFFT_STEP(i, point) NFFT_STEP_V(i, point, 0ull)
 #else
 #define NFFT_TRACE(slot, value) do { } while (0)
 #define NFFT_STEP(i, point) do { } while (0)
+#define NFFT_STEP_V(i, point, extra) do { } while (0)
 #endif
 
 namespace {
@@ -77,15 +84,17 @@ constexpr int kSlots = kKB * kNKB;
 constexpr int kMfmaThreads = 1024;
 constexpr int kMaxSegSlabs = 128;   // planes of one work item (a range of M / runs slabs or a piece of it)
 constexpr int kMaxSweep = kMaxSegSlabs + 2 * kMaxCutoff;  // slabs it sweeps: the owned variant adds 2m+1 halo slabs
-constexpr int kPsiStride = 20; // floats per row of the psi1 table (16 + 4: conflict-free ds_read_b128 over rows)
+constexpr float kPsiScale = 16.0f;  // psi1 <= 1 enters its f16 split times 16: psi1 * (x' psi0 * 2^11) <= 2^15 fits f16, and the
+                                    // lo parts of the three central taps on either side are normal f16 numbers
 
 // Operands of one batch of K-blocks, double-buffered: while the waves run the MFMAs of batch i they already build
 // the operands of batch i + 1.
 template <int W>
 struct __align__(16) MfmaOps {
     f16x8 bfrag[kNKB][2][2][64];          // [K-block][column tile][hi/lo][lane]
-    float psi1[kNKB][32][kPsiStride];     // [K-block][row][point]
-    float atab[kNKB][W][kKB];             // [K-block][axis-0 tap][point]   x' * psi0
+    _Float16 p1[kNKB][2][2][32][8];       // [K-block][hi/lo][point >> 3][row][point & 7]   16 psi1, f16 split: lane (row, h) of an
+                                          // owner wave reads its 8 points with one ds_read_b128 at 16 * lane (no bank conflict)
+    _Float16 a0[kNKB][W][2][kKB];         // [K-block][axis-0 tap][hi/lo][point]   2^11 x' psi0, f16 split
     int slab[kNKB];
     int halves[kNKB];                     // bit t: some tap of the K-block lies in column tile t (else its MFMAs are skipped)
 };
@@ -206,7 +215,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     NFFT_TRACE(1, __builtin_amdgcn_s_memrealtime());
     if (tid == 0) L.inv_xscale = 1.0f / xscale;  // (visible behind the barriers of the schedule set-up below)
     const float unscale =
-        __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(xscale * norm * (1.0f / (kOpScale * kOpScale)))));
+        __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(xscale * norm * (1.0f / (kOpScale * kOpScale * kPsiScale)))));
     float *const gplane = grid + (int64_t)plane_local * g.cells;
 
     f32x16 acc0 = 0.0f, acc1 = 0.0f;
@@ -223,7 +232,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     const int st = tid - kStageWave0 * 64;  // slot of a staging thread, in [0, kSlots)
     const bool stager = (unsigned)st < (unsigned)kSlots;
 
-    auto flush = [&]() {
+    auto flush = [&]() __attribute__((always_inline)) {
         if constexpr (OWNED) {
             // every owned plane is written exactly once, whether or not points reached it
             if (owner && myz >= sb && myz < se) {  // (the builder waves own nothing)
@@ -249,35 +258,41 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
             acc1 = 0.0f;
             dirty = false;
         } else if (dirty) {
-            const int gz = wrap(myz, g.M);
+            // (the tile origin and the lane's position pass through an empty asm: everything derived from them -- the 32
+            // wrapped row offsets of the boundary pencils above all -- is then computed HERE, once per flush, instead of being
+            // hoisted out of the K-block loop into ~35 registers the kernel does not have: it sat at the 128-VGPR limit with
+            // 15 VGPRs and 62 SGPRs spilled to scratch until round 4)
+            int o1 = tb1 - m, o2 = tb2 - m, M = g.M, hh = h, rr = r32;
+            asm volatile("" : "+s"(o1), "+s"(o2), "+s"(M), "+v"(hh), "+v"(rr));
+            const int gz = wrap(myz, M);
             const float zscale = ((myz + m) & 1) ? -unscale : unscale;  // plane s - m + l0: parity of s + l0 + m
             // (no test for zero: a plane that received points has few zero cells, and the test costs as much
             // instruction issue as the atomic)
-            if (tb1 - m >= 0 && tb1 - m + 32 <= g.M) {
+            if (o1 >= 0 && o1 + 32 <= M) {
                 // the tile's 32 rows do not cross the periodic boundary (all pencils but the first and the last of a
                 // column of pencils): one 32-bit offset per lane and column tile, the rows are wave-uniform strides
                 // from it -- 2 vector instructions per atomic instead of 14 (the flush was 13 % of the kernel's)
-                float *const pbase = gplane + (int64_t)gz * g.M * g.M;
+                float *const pbase = gplane + (int64_t)gz * M * M;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const int gc = wrap_near(tb2 - m + 32 * t + r32, g.M);
-                    const unsigned off0 = (unsigned)((tb1 - m + 4 * h) * g.M + gc);
+                    const int gc = wrap_near(o2 + 32 * t + rr, M);
+                    const unsigned off0 = (unsigned)((o1 + 4 * hh) * M + gc);
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
-                        const unsigned row_off = (unsigned)(((reg & 3) + 8 * (reg >> 2)) * g.M);  // wave-uniform
+                        const unsigned row_off = (unsigned)(((reg & 3) + 8 * (reg >> 2)) * M);  // wave-uniform
                         atomicAdd(pbase + (off0 + row_off), (t == 0 ? acc0[reg] : acc1[reg]) * zscale);
                     }
                 }
             } else {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const int gc = wrap_near(tb2 - m + 32 * t + r32, g.M);
+                    const int gc = wrap_near(o2 + 32 * t + rr, M);
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
-                        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
                         const float v = (t == 0 ? acc0[reg] : acc1[reg]) * zscale;
-                        const int gr = wrap_near(tb1 - m + row, g.M);
-                        atomicAdd(gplane + ((int64_t)gz * g.M + gr) * g.M + gc, v);
+                        const int gr = wrap_near(o1 + row, M);
+                        atomicAdd(gplane + ((int64_t)gz * M + gr) * M + gc, v);
                     }
                 }
             }
@@ -429,16 +444,19 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     // ---- operands of a batch: three wave-sized tasks per K-block, handed out through an LDS counter so that the
     // waves whose plane lies outside the batch's windows (6 of 16 for m = 4) build them while the others run MFMAs.
     // Only the 16 (2m+2) taps per axis are evaluated and scattered into zero-filled tables.
+    [[maybe_unused]] int tasks_taken = 0;  // (trace builds only)
     auto build_tasks = [&](const MfmaStage &S, MfmaOps<W> &O, const int nkb, int *counter) {
+        tasks_taken = 0;
         while (true) {
             // all 64 lanes add 1 (the compiler folds this into one ds_add of 64 per wave): the counter runs in units of
             // 64, lane 0 sees the wave's base value
             const int j = __builtin_amdgcn_readfirstlane(atomicAdd(counter, 1)) >> 6;
             if (j >= nkb) break;
+            ++tasks_taken;
             // One task = the three operand tables of K-block j.  A task is a chain of LDS round trips (counter, inputs,
             // zero fill, scattered writes), not arithmetic: as three tasks of one table each the builds took 57 % of the
-            // workgroup's wave time (profiles/r03_experiments.md); in one task their chains overlap and the point's
-            // inputs are read once.
+            // workgroup's wave time (profiles/r03_experiments.md), as two (B side / A side) they change nothing
+            // (profiles/r04_experiments.md); in one task the chains overlap and the point's inputs are read once.
             // ---- zero fills: B fragments [column tile][hi/lo][lane = 32 (k / 8) + column] element k % 8, psi1 [row][point]
             {
                 const f16x8 zero = (_Float16)0.0f;
@@ -446,9 +464,10 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                 O.bfrag[j][0][1][lane] = zero;
                 O.bfrag[j][1][0][lane] = zero;
                 O.bfrag[j][1][1][lane] = zero;
-                f32x4 *pz = (f32x4 *)&O.psi1[j][0][0];
+                f32x4 *pz = (f32x4 *)&O.p1[j][0][0][0][0];  // 2 x 2 x 32 x 8 halves = 128 x 16 bytes
                 const f32x4 zero4 = 0.0f;
-                for (int e = lane; e < 32 * kPsiStride / 4; e += 64) pz[e] = zero4;
+                pz[lane] = zero4;
+                pz[lane + 64] = zero4;
             }
             asm volatile("" ::: "memory");  // the scattered writes below must stay behind the zero fills
             // lane = 4 k + g: point k of the K-block, taps g, g + 4, g + 8 (, g + 12) -- the point's cell and fraction
@@ -478,19 +497,27 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                         touched |= 1 + (col >> 5);
                     }
                 }
-                // psi1 table [row][point]
+                // psi1 table [row][point] and axis-0 table [tap][point] (x' psi0), both as f16 splits: the owners form the
+                // split of the product psi1 * (x' psi0) from them in packed f16 arithmetic (split_product_f16x4).  Odd planes
+                // accumulate the negated sum (undone at the flush): the sign-independent part of the MFMA accumulation's
+                // truncation bias then alternates from plane to plane
                 {
                     const int row = c1v - m + l;
-                    const float d = f1v + (float)(m - l);
-                    const float v = __builtin_amdgcn_exp2f(sc * d * d);
-                    if (l < W && (unsigned)row < 32u) O.psi1[j][row][k] = v;
-                }
-                // axis-0 table [tap][point]: x' psi0.  Odd planes accumulate the negated sum (undone at the flush): the
-                // sign-independent part of the MFMA accumulation's truncation bias then alternates from plane to plane
-                {
-                    const float d = f0v + (float)(m - l);
+                    const float d1 = f1v + (float)(m - l);
+                    const float v1 = __builtin_amdgcn_exp2f(sc * d1 * d1) * kPsiScale;
+                    const float d0 = f0v + (float)(m - l);
                     const float sgn = ((sl + l) & 1) ? -kOpScale : kOpScale;
-                    if (l < W) O.atab[j][l][k] = xv * __builtin_amdgcn_exp2f(sc * d * d) * sgn;
+                    const float va = xv * __builtin_amdgcn_exp2f(sc * d0 * d0) * sgn;
+                    unsigned hi, lo;  // low halves: psi1, high halves: x' psi0
+                    split_pair(v1, va, hi, lo);
+                    if (l < W) {
+                        O.a0[j][l][0][k] = __builtin_bit_cast(_Float16, (unsigned short)(hi >> 16));
+                        O.a0[j][l][1][k] = __builtin_bit_cast(_Float16, (unsigned short)(lo >> 16));
+                        if ((unsigned)row < 32u) {
+                            O.p1[j][0][k >> 3][row][k & 7] = __builtin_bit_cast(_Float16, (unsigned short)hi);
+                            O.p1[j][1][k >> 3][row][k & 7] = __builtin_bit_cast(_Float16, (unsigned short)lo);
+                        }
+                    }
                 }
             }
             // the plan orders a slab's points by column group (common.h): most K-blocks touch one tile only
@@ -519,19 +546,15 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
             }
             const int l0 = myz - s + m;  // axis-0 tap of this K-block's points that lands on my plane
             if ((unsigned)l0 < (unsigned)W && (!OWNED || myz < se)) {
-                const f32x4 *pp = (const f32x4 *)&O.psi1[j][r32][8 * h];
-                const f32x4 *pa = (const f32x4 *)&O.atab[j][l0][8 * h];
-                const f32x4 p0 = pp[0], p1 = pp[1], a0 = pa[0], a1 = pa[1];
-                unsigned h0, h1, h2, h3, q0, q1, q2, q3;
-                split_product_pair(p0.x, a0.x, p0.y, a0.y, h0, q0);
-                split_product_pair(p0.z, a0.z, p0.w, a0.w, h1, q1);
-                split_product_pair(p1.x, a1.x, p1.y, a1.y, h2, q2);
-                split_product_pair(p1.z, a1.z, p1.w, a1.w, h3, q3);
-                const u32x4 uh = {h0, h1, h2, h3}, ul = {q0, q1, q2, q3};
+                // A fragment of my plane: (hi, lo) of psi1[row][point] * (x' psi0)[tap l0][point] for the lane's row and
+                // 8 points, from the f16 splits of the two factors -- 4 ds_read_b128 and 16 packed f16 instructions
+                const u32x4 ph = *(const u32x4 *)&O.p1[j][0][h][r32][0], pl = *(const u32x4 *)&O.p1[j][1][h][r32][0];
+                const u32x4 xh = *(const u32x4 *)&O.a0[j][l0][0][8 * h], xl = *(const u32x4 *)&O.a0[j][l0][1][8 * h];
+                u32x4 uh, ul;
+                split_product_f16x4(ph, pl, xh, xl, uh, ul);
                 const f16x8 ah = __builtin_bit_cast(f16x8, uh), al = __builtin_bit_cast(f16x8, ul);
-                // one column tile after the other (their B fragments are not live at the same time: the kernel sits at
-                // the register limit; interleaving the two chains measured slower in both variants: scatter 2.2 vs
-                // 1.65 ms at C3 with 96 bytes of spills, owner-computes 11.5 vs 9.7 ms at C4-share without any)
+                // one column tile after the other, each a chain of three MFMAs on its own accumulator (requesting the B
+                // fragments ahead of the packed arithmetic, alternating the two chains, or both: no gain, profiles/r04_experiments.md)
                 if (hv & 1) {
                     const f16x8 b0h = O.bfrag[j][0][0][lane], b0l = O.bfrag[j][0][1][lane];
                     if constexpr (OWNED) {
@@ -591,7 +614,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
         if (i + 1 < nbatch)
             build_tasks(L.stag[(i + 1) & 1], L.ops[(i + 1) & 1], min(kNKB, total - (i + 1) * kNKB),
                         &L.task_counter[(i + 1) & 1]);
-        NFFT_STEP(i, 2);
+        NFFT_STEP_V(i, 2, (unsigned long long)tasks_taken << 56);
         barrier_lds_only();
         NFFT_STEP(i, 3);
     }
