@@ -36,6 +36,12 @@ MFMA_F16_FLOPS = 2.5e15        # dense f16 matrix peak (MI355X_MICROARCH.md)
 ARITHMETIC = ("fp32 in / fp32 out; window sums on v_mfma_f32_32x32x16_f16 with two-way f16-split operands "
               "(hi*hi + hi*lo + lo*hi, ~22 significant bits) and fp32 accumulation; FFT and roll-off in fp32")
 KERNEL_SOURCES = ("spread_mfma.hip", "common.h", "mfma_split.h", "window.h")
+TRAFFIC_RECORD = "r04_spread_traffic.json"
+# gather kernel at C3: FETCH_SIZE x 2 + WRITE_SIZE from the committed PMC passes (builder-measured)
+INTERP_TRAFFIC = {"bytes": None, "source": "profiles/r04_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, builder-measured)"}
+TRAFFIC_SOURCE = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE (x2, the gfx950 correction) and WRITE_SIZE passes of this command, "
+                  "taken by the builder (scripts/profile_round.sh) and replayed here while the kernel's name, the workload and "
+                  "the hash of the kernel's source files still match; null otherwise -- not measured by this run" % TRAFFIC_RECORD)
 
 
 def parse():
@@ -52,7 +58,7 @@ def parse():
                          "or 8 Gaussian clusters (sigma 0.05, SURVEY.md 8(d)'s robustness case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the per-config legs (headline line only)")
-    ap.add_argument("--legs", default="c1,c2,c3clustered,c4share,c5", help="comma-separated legs to run at N=1")
+    ap.add_argument("--legs", default="c1,c2,c3clustered,c4share,c5,r1,r2,r3", help="comma-separated legs to run at N=1")
     ap.add_argument("--leg-reps", type=int, default=11, help="individually timed steps per leg (median reported)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -92,7 +98,7 @@ def measured_traffic(kernel, workload):
     taken for this kernel, this workload and THIS kernel source (hash of the kernel's source files): after any edit
     of the kernel the figure is stale and the line says null until the PMC passes are re-run."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_spread_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", TRAFFIC_RECORD)) as f:
             t = json.load(f)
         if t.get("kernel") == kernel and t.get("workload") == workload and t.get("source_hash") == kernel_source_hash():
             return t["fetch_bytes_corrected"] + t["write_bytes"]
@@ -246,11 +252,24 @@ def main():
 
     legs = {}
 
-    def leg_adjoint_forward(name, workload, d_, N_, m_, pos_, x_, batch_, units, unit_name):
+    def guarded(name, fn):
+        """A leg that fails is recorded as {"error": ...}; the headline line is printed whatever the legs do."""
+        try:
+            return fn()
+        except Exception as e:  # noqa: BLE001 (a bench leg must not take the result line down with it)
+            legs[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
+            try:
+                _lib.profile_enable(False)
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                pass
+            return None
+
+    def leg_adjoint_forward(name, workload, d_, N_, m_, pos_, x_, batch_, units, unit_name, real_output=True):
         def st():
             ops.plan_cache_clear()
             y = tn.nfft_adjoint(x_, pos_, batch_, bandwidth=N_, cutoff=m_)
-            return tn.nfft_forward(y, pos_, batch_, cutoff=m_, real_output=True)
+            return tn.nfft_forward(y, pos_, batch_, cutoff=m_, real_output=real_output)
         med, mn, per_stage = timed_series(st, args.leg_reps)
         legs[name] = {"workload": workload, "ms_per_step_median": med, "ms_per_step_min": mn,
                       "value": units / (med * 1e-3) / 1e6, "unit": unit_name, "stage_ms_per_step": per_stage}
@@ -258,23 +277,24 @@ def main():
 
     want = set() if args.no_legs or distributed else set(s.strip() for s in args.legs.split(",") if s.strip())
     g2 = torch.Generator(device=dev).manual_seed(777)
-    if "c1" in want:
+
+    def leg_c1():
         p1 = make_points(1000, 1, "uniform", g2)
         leg_adjoint_forward("C1", "1-D adjoint+forward, N=64, m=2, 1 000 uniform points, one point set (launch-latency "
                             "bound: 1 KiB grid)", 1, 64, 2, p1, torch.rand((1000,), generator=g2, device=dev), None,
                             1000, "Mpoints/s")
-        del p1
-    if "c2" in want:
+
+    def leg_c2():
         p2 = make_points(100_000, 2, "uniform", g2)
         leg_adjoint_forward("C2", "2-D adjoint+forward, N=128, m=4, 100 000 uniform points, batch_size=1", 2, 128, 4,
                             p2, torch.rand((100_000,), generator=g2, device=dev), None, 100_000, "Mpoints/s")
-        del p2
-    if "c3clustered" in want and (d, N, m) == (3, 256, 4):
+
+    def leg_c3clustered():
         pc = make_points(n, 3, "clusters", g2)
         leg_adjoint_forward("C3-clustered", "C3 with %d points in 8 Gaussian clusters (sigma 0.05) instead of uniform" % n,
                             3, N, m, pc, x, None, n, "Mpoints/s")
-        del pc
-    if "c4share" in want:
+
+    def leg_c4share():
         B4, C4, n4 = 4, 64, 100_000
         p4 = make_points(B4 * n4, 3, "uniform", g2)
         b4 = torch.arange(B4 * n4, device=dev) // n4
@@ -292,8 +312,8 @@ def main():
                 "bound": "hbm", "algorithmic_bytes_per_step": alg4, "ms_per_step": sp4,
                 "achieved": alg4 / (sp4 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": alg4 / (sp4 * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        del p4, b4, x4
-    if "c5" in want:
+
+    def leg_c5():
         n5 = 1_000_000
         src = (torch.rand((n5, 3), generator=g2, device=dev) - 0.5) * 0.5  # radius-1/4 box (test_fastsum.py:17-18)
         tgt = (torch.rand((n5, 3), generator=g2, device=dev) - 0.5) * 0.5
@@ -308,57 +328,100 @@ def main():
                                   "targets, 3-D N=256, m=4 (one native call, plans rebuilt every step)",
                       "ms_per_step_median": med, "ms_per_step_min": mn, "value": (2 * n5) / (med * 1e-3) / 1e6,
                       "unit": "Mpoints/s (sources + targets)", "stage_ms_per_step": per_stage}
-        del src, tgt, x5, co
-    torch.cuda.empty_cache()
+
+    # The reference's own stated regime (torch_nfft/nfft.py:150-156: d <= 3, N in {16, 32, 64}, many points, m <= 8; its tests run
+    # d=2, N=16, 3 x 1000 points, 10 columns: test/test_adjoint.py:21-32) -- complex spectra back into the forward transform
+    def leg_r1():
+        B, npts = 8, 100_000
+        p = make_points(B * npts, 3, "uniform", g2)
+        b = torch.arange(B * npts, device=dev) // npts
+        leg_adjoint_forward("R1", "reference regime: 3-D adjoint+forward, N=32, m=3 (the API default), 8 point sets x 100 000 "
+                            "uniform points, one real column", 3, 32, 3, p, torch.rand((B * npts,), generator=g2, device=dev),
+                            b, B * npts, "Mpoints/s", real_output=False)
+
+    def leg_r2():
+        p = make_points(1_000_000, 3, "uniform", g2)
+        leg_adjoint_forward("R2", "reference regime: 3-D adjoint+forward, N=64, m=4, 10^6 uniform points, one point set",
+                            3, 64, 4, p, torch.rand((1_000_000,), generator=g2, device=dev), None, 1_000_000, "Mpoints/s",
+                            real_output=False)
+
+    def leg_r3():
+        B, npts, C = 3, 1000, 10
+        p = (torch.rand((B * npts, 2), generator=g2, device=dev) - 0.5) * 0.5  # radius 1/4 (test_adjoint.py:24)
+        b = torch.arange(B * npts, device=dev) // npts
+        leg_adjoint_forward("R3", "the reference's test shape (test/test_adjoint.py:21-32): 2-D adjoint+forward, N=16, m=3, "
+                            "3 point sets x 1 000 points, 10 real columns", 2, 16, 3, p,
+                            torch.rand((B * npts, C), generator=g2, device=dev), b, B * npts * C, "M point-columns/s",
+                            real_output=False)
+
+    for key, name, fn in (("c1", "C1", leg_c1), ("c2", "C2", leg_c2), ("c3clustered", "C3-clustered", leg_c3clustered),
+                          ("c4share", "C4-share", leg_c4share), ("c5", "C5", leg_c5), ("r1", "R1", leg_r1),
+                          ("r2", "R2", leg_r2), ("r3", "R3", leg_r3)):
+        if key in want and (key != "c3clustered" or (d, N, m) == (3, 256, 4)):
+            guarded(name, fn)
+            torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ N > 1: C4 sharded for real (RCCL all-gather)
+    leg_hung = False
     if distributed:
-        B4, C4, n4 = 4 * world, 64, 100_000
-        g4 = torch.Generator(device=dev).manual_seed(4242)  # same inputs on every rank: the wrapper's contract
-        p4 = torch.rand((B4 * n4, 3), generator=g4, device=dev) - 0.5
-        b4 = torch.arange(B4 * n4, device=dev) // n4
-        x4 = torch.randn((B4 * n4, C4), generator=g4, device=dev)
-        # The timed pipeline keeps the spectra sharded: adjoint(gather=False) -> this rank's [B_r, N^3, C] slab ->
-        # forward(x_is_local=True) -> all-gather of the [n, C] rows (102 MB per rank).  Nothing replicates the 34.4 GB of
-        # spectra.  The all-gather of the spectra is timed apart, as the optional step it is (callers that want the
-        # full spectrum on every rank).
-        t_adj, t_fwd, t_total, t_gather = [], [], [], []
-        for it in range(2 + 5):
-            ops.plan_cache_clear()
-            barrier()
-            t0 = time.perf_counter()
-            ya = tnd.nfft_adjoint(x4, p4, b4, bandwidth=128, cutoff=4, gather=False)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            yf = tnd.nfft_forward(ya, p4, b4, cutoff=4, real_output=True, gather=True, x_is_local=True)
-            barrier()
-            t2 = time.perf_counter()
-            if it >= 2:
-                t_adj.append(max_over_ranks(t1 - t0)); t_fwd.append(max_over_ranks(t2 - t1))
-                t_total.append(max_over_ranks(t2 - t0))
-            del yf
-            if it >= 4:  # optional: the full spectrum on every rank
-                sizes = [tnd.batch_range(B4, r, world)[1] - tnd.batch_range(B4, r, world)[0] for r in range(world)]
+        def leg_c4_sharded():
+            Br, C4, n4 = 4, 64, 100_000           # per rank: 4 point sets (B = 4 N in all, 32 at N = 8: the configuration C4 names)
+            B4 = Br * world
+            g4 = torch.Generator(device=dev).manual_seed(4242 + rank)  # every rank makes ITS point sets: nothing is replicated
+            p4 = torch.rand((Br * n4, 3), generator=g4, device=dev) - 0.5
+            b4 = torch.arange(Br * n4, device=dev) // n4
+            x4 = torch.randn((Br * n4, C4), generator=g4, device=dev)
+            # The timed pipeline keeps inputs and spectra sharded: adjoint(inputs_are_local, gather=False) -> this rank's
+            # [B_r, N^3, C] slab -> forward(inputs_are_local) -> all-gather of the [n, C] rows (102 MB per rank).  Nothing
+            # replicates the points or the 34.4 GB of spectra.  The all-gather of the spectra is timed apart, as the optional
+            # step it is (callers that want the full spectrum on every rank).
+            t_adj, t_fwd, t_total, t_gather = [], [], [], []
+            for it in range(2 + 5):
+                ops.plan_cache_clear()
                 barrier()
-                t3 = time.perf_counter()
-                yfull = tnd._all_gather_rows(ya, sizes, None)
+                t0 = time.perf_counter()
+                ya = tnd.nfft_adjoint(x4, p4, b4, bandwidth=128, cutoff=4, gather=False, inputs_are_local=True,
+                                      local_batch_size=Br)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                yf = tnd.nfft_forward(ya, p4, b4, cutoff=4, real_output=True, gather=True, inputs_are_local=True)
                 barrier()
-                t_gather.append(max_over_ranks(time.perf_counter() - t3))
-                del yfull
-            del ya
-        med = lambda v: sorted(v)[len(v) // 2] * 1e3
-        gathered_bytes = B4 * (128 ** 3) * C4 * 8
-        legs["C4-sharded"] = {
-            "workload": "C4 sharded over %d GPUs: B=%d point sets x 100 000 points, 64 real columns, N=128, m=4; "
-                        "torch_nfft_amd.distributed adjoint (4 sets per rank, spectra stay sharded) -> forward on the "
-                        "rank's own slab (x_is_local) + all-gather of the rows (RCCL)" % (world, B4),
-            "n_gpus": world, "ms_per_step_median": med(t_total), "ms_adjoint_local": med(t_adj),
-            "ms_forward_and_row_gather": med(t_fwd),
-            "optional_all_gather_of_spectra": {
-                "ms": med(t_gather), "bytes_gathered_per_rank": gathered_bytes,
-                "GBps_received_per_rank": gathered_bytes * (world - 1) / world / (med(t_gather) * 1e-3) / 1e9},
-            "value": B4 * n4 * C4 / (med(t_total) * 1e-3) / 1e6, "unit": "M point-columns/s"}
-        del p4, b4, x4
+                t2 = time.perf_counter()
+                if it >= 2:
+                    t_adj.append(max_over_ranks(t1 - t0)); t_fwd.append(max_over_ranks(t2 - t1))
+                    t_total.append(max_over_ranks(t2 - t0))
+                del yf
+                if it >= 4:  # optional: the full spectrum on every rank
+                    barrier()
+                    t3 = time.perf_counter()
+                    yfull = tnd._all_gather_rows(ya, [Br] * world, None)
+                    barrier()
+                    t_gather.append(max_over_ranks(time.perf_counter() - t3))
+                    del yfull
+                del ya
+            med = lambda v: sorted(v)[len(v) // 2] * 1e3
+            gathered_bytes = B4 * (128 ** 3) * C4 * 8
+            legs["C4-sharded"] = {
+                "workload": "C4 sharded over %d GPUs: B=%d point sets x 100 000 points, 64 real columns, N=128, m=4; every "
+                            "rank holds only its 4 point sets (inputs_are_local); torch_nfft_amd.distributed adjoint (spectra "
+                            "stay sharded) -> forward on the rank's own slab + all-gather of the rows (RCCL)" % (world, B4),
+                "n_gpus": world, "ms_per_step_median": med(t_total), "ms_adjoint_local": med(t_adj),
+                "ms_forward_and_row_gather": med(t_fwd),
+                "optional_all_gather_of_spectra": {
+                    "ms": med(t_gather), "bytes_gathered_per_rank": gathered_bytes,
+                    "GBps_received_per_rank": gathered_bytes * (world - 1) / world / (med(t_gather) * 1e-3) / 1e9},
+                "value": B4 * n4 * C4 / (med(t_total) * 1e-3) / 1e6, "unit": "M point-columns/s"}
+
+        # The leg runs in a helper thread that the main thread waits for with a limit: an exception is recorded like that
+        # of any other leg, and a collective that never returns (the one failure a try/except cannot see) leaves the
+        # headline line intact -- the process then leaves through os._exit once the line is out.
+        import threading
+        worker = threading.Thread(target=lambda: guarded("C4-sharded", leg_c4_sharded), daemon=True)
+        worker.start()
+        worker.join(float(os.environ.get("NFFT_BENCH_LEG_TIMEOUT", "240")))
+        if worker.is_alive():
+            leg_hung = True
+            legs["C4-sharded"] = {"error": "timeout: the sharded leg did not return (a collective is stuck?)"}
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -409,12 +472,27 @@ def main():
             },
             "roofline": {
                 "kernel": kname,
-                "bound": "hbm",
+                # The figures below are the north star's: algorithmic HBM bytes over the launch time against the HBM peak.
+                # What BINDS the kernel is not HBM: its window sums are matrix work (0.86 PFLOP issued per launch) fed by
+                # vector instructions, and by the SQ counters the SIMDs spend ~80 % of the launch issuing the two
+                # (profiles/r03_pmc_sq_counters.txt, profiles/r04_experiments.md); `issue_roof` carries that side.
+                "bound": "mfma" if mfma else "hbm",
+                "bound_note": "matrix + vector instruction issue (they do not overlap on a SIMD); achieved / peak / frac are "
+                              "the HBM figures BASELINE.json's metric asks for, issue_roof the binding side",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(kname, workload),
+                "traffic_source": TRAFFIC_SOURCE,
+                "issue_roof": {
+                    "mfma_f16_issued_tflops": (mfma_flops / (sp_avg * 1e-3)) / 1e12 if sp_avg > 0 else 0.0,
+                    "mfma_f16_peak_tflops": MFMA_F16_FLOPS / 1e12,
+                    "frac_of_mfma_f16_peak": (mfma_flops / (sp_avg * 1e-3)) / MFMA_F16_FLOPS if sp_avg > 0 else 0.0,
+                    "valu_plus_mfma_busy_frac_of_simd_cycles": 0.82,
+                    "busy_frac_source": "profiles/r03_pmc_sq_counters.txt (SQ_ACTIVE_INST_VALU x 4 + SQ_VALU_MFMA_BUSY_CYCLES over "
+                                        "the SIMD cycles of the launch; builder-measured, not re-measured by this run)",
+                },
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": sp_avg,
                 "launches": sp_cnt,
@@ -425,6 +503,20 @@ def main():
                 # (coefficient gather + zero fill + spreading), and with the point plan on top
                 "achieved_incl_gather_zero": alg_bytes / (pipe_ms * 1e-3) / 1e9 if pipe_ms > 0 else 0.0,
                 "achieved_incl_gather_zero_plan": alg_bytes / ((pipe_ms + plan_ms) * 1e-3) / 1e9 if pipe_ms > 0 else 0.0,
+            },
+            # the forward gather (interp_stream_kernel at this size): every point read once, its result written once, the
+            # complex grid -- here a real one, the C2R output -- read once: SURVEY.md 8(d) counts n (4 d + 4 C) + M^d 8
+            "roofline_interp": {
+                "kernel": "interp_stream_kernel<%d, false, 3>" % W if mfma else "interp_kernel<%d,%d>" % (d, W),
+                "bound": "mfma" if mfma else "hbm",
+                "bound_note": "as the spreading kernel: matrix + vector instruction issue of its consumer waves",
+                "algorithmic_bytes_per_launch": n * (4 * d + 4) + (M ** d) * 8,
+                "avg_launch_ms": per_stage.get("interp", 0.0),
+                "achieved": (n * (4 * d + 4) + (M ** d) * 8) / (per_stage["interp"] * 1e-3) / 1e9 if per_stage.get("interp") else 0.0,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (n * (4 * d + 4) + (M ** d) * 8) / (per_stage["interp"] * 1e-3) / 1e9 / HBM_PEAK_GBS if per_stage.get("interp") else 0.0,
+                "traffic": INTERP_TRAFFIC.get("bytes") if (d, N, m, n) == (3, 256, 4, 10_000_000) else None,
+                "traffic_source": INTERP_TRAFFIC.get("source"),
             },
             "stage_ms_per_launch": per_stage,
             "stage_timers": "timed region: HIP events around the spreading stage only (roofline.avg_launch_ms); the stage "
@@ -438,6 +530,9 @@ def main():
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     if distributed:
+        if leg_hung:
+            sys.stderr.flush()
+            os._exit(0)  # (a stuck collective: no barrier, no tear-down -- the result line is out)
         dist.barrier()
         dist.destroy_process_group()
 

@@ -35,13 +35,14 @@ extern "C" {
 #define NFFT_HIP_EHIP 4       /* HIP runtime error (reference aborts the process, cuda_utils.cu:7-14; we report) */
 #define NFFT_HIP_EKERNEL 5    /* a kernel of an earlier call on this device reported a fault (nfft_hip_check_status) */
 
-#define NFFT_HIP_ABI_VERSION 3
+#define NFFT_HIP_ABI_VERSION 4
 
 int nfft_hip_abi_version(void);
 const char *nfft_hip_last_error(void);
 
 /* Faults that only a running kernel can detect -- a bounded wait inside the streamed interpolation kernel ran out,
- * a batch index outside [0, batch_size) in the middle of the batch vector -- are raised in a host-mapped status block
+ * a batch index outside [0, batch_size) in the middle of the batch vector, a cached plan whose points have changed
+ * (nfft_hip_plan_verify) -- are raised in a host-mapped status block
  * of the device and turned into an error by the NEXT entry point called on that device: it returns NFFT_HIP_EKERNEL
  * (NFFT_HIP_EINVAL for the batch vector) without running, and clears the flag.  nfft_hip_check_status looks at the
  * block on demand; with synchronize != 0 it first waits for `stream`, so that a fault of the work just enqueued is
@@ -124,6 +125,16 @@ int64_t nfft_hip_plan_bytes(const nfft_hip_problem *p);
  * counting-sorted by tile and the window is re-evaluated in registers by the consumers. */
 int nfft_hip_plan_points(const nfft_hip_problem *p, const float *pos, const int64_t *batch,
                          void *plan, int64_t plan_bytes, void *stream);
+
+/* Seal and verification of a plan that is kept across calls.  nfft_hip_plan_seal stores a 64-bit checksum of pos (and
+ * batch) in the plan; nfft_hip_plan_verify recomputes it from the arrays as they are NOW (one streaming pass, ~25 us for
+ * 10^7 3-D points) and raises a device fault when it differs: the next entry point on the device returns
+ * NFFT_HIP_EINVAL ("stale point plan"), nfft_hip_check_status sees it on demand.  A cache of plans keyed on buffer
+ * identity (core.so's: tensor address + version counter) cannot see a write that bypasses its key; the reference has no
+ * such state -- it recomputes shifts and psi in every call (csrc/cuda/core_cuda.cu:188-211) -- so a drop-in must not
+ * return a transform of points that are no longer there without saying so. */
+int nfft_hip_plan_seal(const nfft_hip_problem *p, const float *pos, const int64_t *batch, void *plan, void *stream);
+int nfft_hip_plan_verify(const nfft_hip_problem *p, const float *pos, const int64_t *batch, void *plan, void *stream);
 
 /* Spreading (adjoint gridding):  grid[(b*Cr + cr), u] += xr[i, cr] * prod_k psi_k(i, u_k)
  * over real columns cr (a complex x is viewed as 2C real columns).  Replaces

@@ -5,7 +5,7 @@
 set -e
 BASE=$1; shift
 OBJS=""
-for f in api.hip binning.hip spread.hip spread_reg.hip spread_mfma.hip interp.hip interp_mfma.hip interp_cols.hip interp_stream.hip smallgrid.hip spectral.hip colfft.hip coeffs.hip fft.cpp; do
+for f in api.hip binning.hip spread.hip spread_reg.hip spread_mfma.hip interp.hip interp_mfma.hip interp_cols.hip interp_stream.hip smallgrid.hip spectral.hip colfft.hip coeffs.hip selftest.hip fft.cpp; do
   if [ "$f" != "$BASE" ]; then OBJS="$OBJS torch_nfft_amd/_obj/$f.o"; fi
 done
 for spec in "$@"; do

@@ -478,3 +478,99 @@ def test_unsorted_batch_vector_is_reported(tn):
     y = tn.nfft_adjoint(dev(x), pos, dev(batch), bandwidth=N, cutoff=m)
     ops.check_status()
     assert rel_l2(host(y), nfft_ref.nfft_adjoint(x, host(pos), batch, N=N, m=m)) < 2e-6
+
+
+def test_stale_cached_plan_is_reported(tn):
+    """A write to ``pos`` behind the version counter (``pos.data``: the cache key cannot see it) after a plan has entered the
+    cache: the next call on those points hits the cache, the seal of the plan does not match the points any more, and
+    the fault surfaces at the next operator / ``check_status()`` -- instead of a transform of points that are no longer
+    there (the reference recomputes shifts and psi in every call: csrc/cuda/core_cuda.cu:188-211)."""
+    from torch_nfft_amd import ops
+    rng = np.random.default_rng(23)
+    n, N, m = 20000, 32, 3
+    pos_a = (rng.random((n, 3)) - 0.5).astype(np.float32)
+    pos_b = (rng.random((n, 3)) - 0.5).astype(np.float32)
+    batch = np.sort(rng.integers(0, 3, n)).astype(np.int64)
+    batch[0], batch[-1] = 0, 2
+    x = rng.standard_normal(n).astype(np.float32)
+    pos, xt, bt = dev(pos_a), dev(x), dev(batch)
+    ops.plan_cache_clear()
+    ops.check_status()
+    s0 = ops.plan_cache_stats()
+    y = tn.nfft_adjoint(xt, pos, bt, bandwidth=N, cutoff=m)
+    assert rel_l2(host(y), nfft_ref.nfft_adjoint(x, pos_a, batch, N=N, m=m)) < 2e-6
+    y = tn.nfft_adjoint(xt, pos, bt, bandwidth=N, cutoff=m)   # a genuine hit: verified, clean
+    ops.check_status()
+    assert ops.plan_cache_stats()["hits"] == s0["hits"] + 1
+    version = pos._version
+    pos.data.copy_(dev(pos_b))                                  # the version counter does not move
+    assert pos._version == version
+    tn.nfft_adjoint(xt, pos, bt, bandwidth=N, cutoff=m)          # hits the stale plan
+    with pytest.raises(RuntimeError, match="stale point plan"):
+        ops.check_status()
+    ops.check_status()                                           # (the flag is cleared by the report)
+    # the same for the batch vector
+    ops.plan_cache_clear()
+    tn.nfft_adjoint(xt, pos, bt, bandwidth=N, cutoff=m)
+    b2 = batch.copy()
+    b2[n // 2:] = 2
+    b2[:n // 2] = np.minimum(b2[:n // 2], 1)
+    bt.data.copy_(dev(np.sort(b2)))
+    with pytest.raises(RuntimeError, match="stale point plan"):
+        tn.nfft_adjoint(xt, pos, bt, bandwidth=N, cutoff=m)
+        ops.check_status()
+    try:
+        ops.check_status()
+    except RuntimeError:
+        pass
+    # after clearing the cache the new points are transformed
+    ops.plan_cache_clear()
+    bt2 = dev(np.sort(b2))
+    y = tn.nfft_adjoint(xt, pos, bt2, bandwidth=N, cutoff=m)
+    ops.check_status()
+    assert rel_l2(host(y), nfft_ref.nfft_adjoint(x, pos_b, np.sort(b2), N=N, m=m)) < 2e-6
+    # verification can be switched off by callers who never write behind the counter
+    ops.plan_cache_verify(False)
+    try:
+        pos.data.copy_(dev(pos_a))
+        tn.nfft_adjoint(xt, pos, bt2, bandwidth=N, cutoff=m)
+        ops.check_status()                                       # (stale, and nobody looks)
+    finally:
+        ops.plan_cache_verify(True)
+        ops.plan_cache_clear()
+
+
+def test_rejected_parameters_the_reference_accepts(tn):
+    """The reference puts no upper bound on the cutoff and does not require an even bandwidth (csrc/cuda/core_cuda.cu:
+    118-137); this library serves m <= 8 (beyond that fp32 gains nothing) and even N.  The deviation is a loud one: the
+    operators raise "Input mismatch" with the reason."""
+    pos = torch.zeros((4, 2), device="cuda")
+    x = torch.zeros((4,), device="cuda")
+    with pytest.raises(RuntimeError, match="Input mismatch: cutoff m must be in 1..8"):
+        tn.nfft_adjoint(x, pos, bandwidth=32, cutoff=9)
+    with pytest.raises(RuntimeError, match="Input mismatch: cutoff m must be in 1..8"):
+        tn.nfft_forward(torch.zeros((1, 32, 32), device="cuda"), pos, cutoff=9)
+    with pytest.raises(RuntimeError, match="Input mismatch.*even"):
+        tn.nfft_adjoint(x, pos, bandwidth=15, cutoff=3)
+    with pytest.raises(RuntimeError, match="Input mismatch.*even"):
+        tn.nfft_forward(torch.zeros((1, 15, 15), device="cuda"), pos, cutoff=3)
+    y = tn.nfft_adjoint(x, pos, bandwidth=32, cutoff=8)  # the largest cutoff served
+    assert y.shape == (1, 32, 32)
+
+
+def test_shard_local_inputs_world1(tn):
+    """`inputs_are_local` of the sharded wrapper with the HIP operators and no process group (world 1): the rank's own point
+    sets in, its slab / rows out -- the same numbers as the plain operators (the multi-rank exchange of the counts is
+    covered under gloo in tests/test_distributed_cpu.py)."""
+    from torch_nfft_amd import distributed as tnd
+    rng = np.random.default_rng(41)
+    n, N, m = 30000, 32, 3
+    pos = dev((rng.random((n, 3)) - 0.5).astype(np.float32))
+    batch = dev(np.sort(rng.integers(0, 3, n)).astype(np.int64))
+    x = dev(rng.standard_normal((n, 2)).astype(np.float32))
+    ya = tnd.nfft_adjoint(x, pos, batch, bandwidth=N, cutoff=m, inputs_are_local=True, local_batch_size=4)
+    ref = tn.nfft_adjoint(x, pos, batch, bandwidth=N, cutoff=m)
+    assert ya.shape[0] == 4 and float(ya[3].abs().max()) == 0.0          # a trailing empty point set
+    assert torch.equal(ya[:3], ref)
+    yf = tnd.nfft_forward(ya, pos, batch, cutoff=m, real_output=True, inputs_are_local=True)
+    assert torch.equal(yf, tn.nfft_forward(ref, pos, batch, cutoff=m, real_output=True))

@@ -158,6 +158,25 @@ def test_fused_empty_input_and_faults(tn):
     # the two sets that do exist are transformed from their own points
     ref = nfft_ref.nfft_adjoint(x[:200], pos[:200], batch[:200], N=64, m=2)
     assert rel_l2(host(yt), ref) < T1N
+    # a bad entry in the MIDDLE of the vector (the ends are fine): the fused kernels look at every row's index, as the
+    # general path's sort does -- out of range, and out of order
+    for bad_value, message in ((7, "Input mismatch"), (0, "Input mismatch: the batch vector is not sorted")):
+        b2 = batch.copy()
+        b2[150] = bad_value
+        bt2 = dev(b2)
+        for fwd in (False, True):
+            ops.plan_cache_clear()
+            ops.check_status()
+            with pytest.raises(RuntimeError, match=message):
+                if fwd:
+                    tn.nfft_forward(torch.zeros((3, 64), dtype=torch.complex64, device="cuda"), pt, bt2, cutoff=2)
+                else:
+                    tn.nfft_adjoint(xt, pt, bt2, bandwidth=64, cutoff=2)
+                ops.check_status()
+            try:
+                ops.check_status()
+            except RuntimeError:
+                pass
 
 
 def test_fused_pair_is_adjoint(tn):

@@ -80,7 +80,10 @@ def test_batch_sharding_arithmetic():
             assert max(b1 - b0 for b0, b1 in rs) - min(b1 - b0 for b0, b1 in rs) <= 1
     batch = torch.tensor([0, 0, 1, 1, 1, 3, 3, 4])
     assert d.point_bounds(batch, 5, 2, 8) == [0, 5, 8]
-    assert d.point_bounds(None, 1, 4, 7) == [0, 7, 7, 7, 7]
+    # a single point set belongs to the rank batch_range gives it to -- the last one -- and so do its points (they sat on
+    # rank 0 until round 4: no rank transformed anything)
+    assert d.point_bounds(None, 1, 4, 7) == [0, 0, 0, 0, 7]
+    assert [d.batch_range(1, r, 4) for r in range(4)] == [(0, 0), (0, 0), (0, 0), (0, 1)]
 
 
 def test_operator_registry_is_native():

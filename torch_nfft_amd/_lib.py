@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NFFT_HIP_LIB") or os.path.join(_HERE, "libnfft_hip.so")
 CORE_PATH = os.path.join(_HERE, "core.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 POINTS_IN_QUARTER_BALL = 1
 
 # every symbol include/nfft_hip.h declares
@@ -28,6 +28,8 @@ SYMBOLS = (
     "nfft_hip_forward_planned",
     "nfft_hip_plan_bytes",
     "nfft_hip_plan_points",
+    "nfft_hip_plan_seal",
+    "nfft_hip_plan_verify",
     "nfft_hip_spread_scratch_bytes",
     "nfft_hip_spread",
     "nfft_hip_interpolate",
@@ -111,6 +113,10 @@ def load():
     lib.nfft_hip_spread_scratch_bytes.restype = i64
     lib.nfft_hip_spread.argtypes = [P, vp, vp, i64, vp, vp, vp]
     lib.nfft_hip_spread.restype = ci
+    lib.nfft_hip_plan_seal.argtypes = [P, vp, vp, vp, vp]
+    lib.nfft_hip_plan_seal.restype = ci
+    lib.nfft_hip_plan_verify.argtypes = [P, vp, vp, vp, vp]
+    lib.nfft_hip_plan_verify.restype = ci
     lib.nfft_hip_interpolate.argtypes = [P, vp, vp, i64, vp, vp]
     lib.nfft_hip_interpolate.restype = ci
     lib.nfft_hip_spectral_multiply.argtypes = [vp, vp, ci, i64, i64, i64, vp]

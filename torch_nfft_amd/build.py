@@ -22,7 +22,7 @@ CORE = os.path.join(HERE, "core.so")
 CORE_SRC = os.path.join(CSRC, "core.cpp")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
-SOURCES = ["api.hip", "binning.hip", "spread.hip", "spread_reg.hip", "spread_mfma.hip", "interp.hip", "interp_mfma.hip", "interp_cols.hip", "interp_stream.hip", "smallgrid.hip", "spectral.hip", "colfft.hip", "coeffs.hip", "fft.cpp"]
+SOURCES = ["api.hip", "binning.hip", "spread.hip", "spread_reg.hip", "spread_mfma.hip", "interp.hip", "interp_mfma.hip", "interp_cols.hip", "interp_stream.hip", "smallgrid.hip", "spectral.hip", "colfft.hip", "coeffs.hip", "selftest.hip", "fft.cpp"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast", "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROCM, "include")]
 

@@ -116,7 +116,10 @@ const char *const kFaultText[kNumFaults] = {
     "the result of that forward transform is invalid",
     "Input mismatch: batch holds an index outside [0, batch_size) (the batch vector must be sorted with "
     "batch[-1] + 1 == batch_size)",
-    "Input mismatch: the batch vector is not sorted (a coefficient exceeds the largest one of its point set's row range)",
+    "Input mismatch: the batch vector is not sorted (a row carries another index than its point set's row range, or a "
+    "coefficient exceeds the largest one of its range)",
+    "stale point plan: pos or batch were modified (behind the version counter) after the cached plan was built; the "
+    "transform that used it is invalid -- clear or disable the plan cache (torch_nfft_amd.ops.plan_cache_clear)",
 };
 }  // namespace
 
@@ -160,6 +163,23 @@ unsigned next_launch_number()
     static std::atomic<unsigned> counter{0};
     unsigned v = ++counter;
     if (v == 0) v = ++counter;  // (0 is what the zeroed ring holds)
+    // A launch takes over the ring row that the launch kTicketLaunches numbers earlier used, and must not do so while that
+    // one is still running (two launches claiming one word from each other would hand work-list entries out twice).
+    // Numbers come in epochs of half a ring; a device that sees a new epoch first waits for everything it has in flight:
+    // whatever ran in the epoch before the previous one -- the only launches that can own this epoch's rows -- is then
+    // finished.  One hipDeviceSynchronize per kTicketLaunches / 2 persistent launches and device (the reference
+    // synchronises the device six times per call, cuda_utils.cu:16).
+    static std::mutex mutex;
+    static unsigned last_epoch[kMaxDevices] = {};
+    const int dev = current_device();
+    if (dev >= 0 && dev < kMaxDevices) {
+        const unsigned epoch = v / (kTicketLaunches / 2) + 1;
+        std::lock_guard<std::mutex> lock(mutex);
+        if (last_epoch[dev] != epoch) {
+            if (last_epoch[dev] != 0) (void)hipDeviceSynchronize();
+            last_epoch[dev] = epoch;
+        }
+    }
     return v;
 }
 
@@ -244,7 +264,7 @@ struct PlanSet {
     bool owned;
     Geom go;
     PlanLayout Lo;
-    int64_t off_own, total;
+    int64_t off_own, off_seal, total;  // off_seal: the plan's seal (kernels.h), behind the sorted points
     const Geom &spread_geom() const { return owned ? go : g; }
     const PlanLayout &spread_layout() const { return owned ? Lo : L; }
     const void *spread_plan(const void *plan) const { return owned ? (const char *)plan + off_own : (const char *)plan; }
@@ -274,6 +294,8 @@ PlanSet plan_set(const nfft_hip_problem *p)
         ps.off_own = align_up(ps.L.total, 256);
         ps.total = ps.off_own + ps.Lo.total;
     }
+    ps.off_seal = align_up(ps.total, 256);
+    ps.total = ps.off_seal + kSealBytes;
     return ps;
 }
 int build_plans(const PlanSet &ps, const float *pos, const int64_t *batch, int64_t n, int64_t B, void *plan, hipStream_t s)
@@ -535,6 +557,22 @@ int nfft_hip_plan_points(const nfft_hip_problem *p, const float *pos, const int6
     if (p->num_points > 0 && !pos) { set_error("Input mismatch: pos is null"); return NFFT_HIP_EINVAL; }
     StageTimer t(kStagePlan, (hipStream_t)stream);
     return build_plans(ps, pos, batch, p->num_points, p->batch_size, plan, (hipStream_t)stream);
+}
+
+int nfft_hip_plan_seal(const nfft_hip_problem *p, const float *pos, const int64_t *batch, void *plan, void *stream)
+{
+    if (int rc = validate(p)) return rc;
+    if (!plan || (p->num_points > 0 && !pos)) { set_error("Input mismatch: null plan or pos"); return NFFT_HIP_EINVAL; }
+    return launch_points_seal(pos, batch, p->num_points, p->dim, (char *)plan + plan_set(p).off_seal, (hipStream_t)stream);
+}
+
+int nfft_hip_plan_verify(const nfft_hip_problem *p, const float *pos, const int64_t *batch, void *plan, void *stream)
+{
+    if (int rc = validate(p)) return rc;
+    if (!plan || (p->num_points > 0 && !pos)) { set_error("Input mismatch: null plan or pos"); return NFFT_HIP_EINVAL; }
+    static std::atomic<unsigned> slot{0};  // eight verifications of one plan may be in flight (on different streams)
+    return launch_points_verify(pos, batch, p->num_points, p->dim, (char *)plan + plan_set(p).off_seal, (int)(slot++ & 7u),
+                                (hipStream_t)stream);
 }
 
 int64_t nfft_hip_spread_scratch_bytes(const nfft_hip_problem *p, int64_t real_columns)

@@ -27,7 +27,7 @@ void set_error(const std::string &msg);
 // fault is pending).  The reference aborts the process on a device error (csrc/cuda/cuda_utils.cu:5-16); here the
 // next call returns NFFT_HIP_EKERNEL.  One int per fault kind: plain system-scope stores, no read-modify-write
 // across the bus.
-enum DeviceFault { kFaultStreamStall = 0, kFaultBatchIndex = 1, kFaultBatchOrder = 2, kNumFaults = 3 };
+enum DeviceFault { kFaultStreamStall = 0, kFaultBatchIndex = 1, kFaultBatchOrder = 2, kFaultStalePlan = 3, kNumFaults = 4 };
 constexpr int kStatusInts = 16;  // ints per device block (a 64-byte line)
 int *device_status_block();      // api.hip: device-visible address of the current device's block (nullptr: none)
 

@@ -55,8 +55,15 @@ struct BatchEnds {
     const void *ptr = nullptr;
     int64_t version = -1, n = -1, first = 0, last = 0;
     int device = -1;
-    at::Tensor keep;  // keeps the address from being recycled
+    // The entry belongs to ONE tensor object, held weakly: it neither pins the vector's memory (80 MB at 10^7 points, four
+    // entries) nor survives the tensor -- an address the allocator hands to another tensor is a miss, not a stale hit.
+    c10::weak_intrusive_ptr<c10::TensorImpl> owner{c10::intrusive_ptr<c10::TensorImpl>()};
     uint64_t last_use = 0;
+    bool owned_by(const at::Tensor &t) const
+    {
+        const auto alive = owner.lock();
+        return alive && alive.get() == t.unsafeGetTensorImpl();
+    }
 };
 struct BatchEndsCache {
     std::mutex mutex;
@@ -78,7 +85,7 @@ void batch_ends(const at::Tensor &batch, int64_t n, int64_t &first, int64_t &las
         if (g_ends.enabled) {
             version = (int64_t)batch._version();
             for (BatchEnds &e : g_ends.entries) {
-                if (e.ptr == ptr && e.version == version && e.n == n && e.device == device) {
+                if (e.ptr == ptr && e.version == version && e.n == n && e.device == device && e.owned_by(batch)) {
                     e.last_use = ++g_ends.tick;
                     first = e.first;
                     last = e.last;
@@ -97,7 +104,8 @@ void batch_ends(const at::Tensor &batch, int64_t n, int64_t &first, int64_t &las
         for (BatchEnds &e : g_ends.entries)
             if (e.last_use < slot->last_use) slot = &e;
         slot->ptr = ptr; slot->version = version; slot->n = n; slot->device = device;
-        slot->first = first; slot->last = last; slot->keep = batch; slot->last_use = ++g_ends.tick;
+        slot->first = first; slot->last = last; slot->last_use = ++g_ends.tick;
+        slot->owner = c10::weak_intrusive_ptr<c10::TensorImpl>(batch.getIntrusivePtr());
     }
 }
 
@@ -184,6 +192,7 @@ struct PlanCache {
     std::mutex mutex;
     PlanEntry entries[2];
     bool enabled = true;
+    bool verify = true;  // seal plans that enter the cache and check the seal on every hit (plan_cache_control 5 / 6)
     int64_t hits = 0, misses = 0;
     uint64_t tick = 0;
     void clear()
@@ -278,18 +287,27 @@ at::Tensor get_plan(const Points &p, const nfft_hip_problem &q)
 {
     std::lock_guard<std::mutex> lock(g_cache.mutex);
     const PlanLookup lk = plan_lookup_key(p, q);
+    const float *pos = p.pos.data_ptr<float>();
+    const int64_t *batch = p.batch.defined() ? p.batch.data_ptr<int64_t>() : nullptr;
     at::Tensor plan = cache_find(lk);
-    if (plan.defined()) return plan;
+    if (plan.defined()) {
+        // A plan from an earlier call: identity + version say the points are the same, the seal checks that they ARE (a
+        // write behind the version counter -- pos.data, a foreign kernel, a DLPack alias -- would otherwise give a wrong
+        // transform silently; the reference recomputes per call, core_cuda.cu:188-211).  One streaming pass over pos /
+        // batch on the caller's stream; a mismatch is reported like every device-side fault: the next operator raises.
+        if (g_cache.verify) check_rc(nfft_hip_plan_verify(&q, pos, batch, plan.data_ptr(), lk.stream));
+        return plan;
+    }
     ++g_cache.misses;
     int64_t nbytes = 0;
     plan = new_plan_buffer(p, q, nbytes);
-    check_rc(nfft_hip_plan_points(&q, p.pos.data_ptr<float>(), p.batch.defined() ? p.batch.data_ptr<int64_t>() : nullptr,
-                                  plan.data_ptr(), nbytes, lk.stream));
+    check_rc(nfft_hip_plan_points(&q, pos, batch, plan.data_ptr(), nbytes, lk.stream));
+    if (lk.use_cache && g_cache.verify) check_rc(nfft_hip_plan_seal(&q, pos, batch, plan.data_ptr(), lk.stream));
     cache_insert(lk, p, plan);
     return plan;
 }
 
-// action: 0 clear, 1 enable, 2 disable (and clear), 3 -> hits, 4 -> misses
+// action: 0 clear, 1 enable, 2 disable (and clear), 3 -> hits, 4 -> misses, 5 / 6 seal verification on / off
 int64_t plan_cache_control(int64_t action)
 {
     std::lock_guard<std::mutex> lock(g_cache.mutex);
@@ -304,6 +322,8 @@ int64_t plan_cache_control(int64_t action)
     case 2: g_cache.enabled = false; g_cache.clear(); return 0;
     case 3: return g_cache.hits;
     case 4: return g_cache.misses;
+    case 5: g_cache.verify = true; return 0;
+    case 6: g_cache.verify = false; return 0;  // (for callers who guarantee they never write behind the version counter)
     }
     TORCH_CHECK(false, "unknown plan cache action");
 }

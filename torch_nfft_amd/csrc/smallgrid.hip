@@ -147,6 +147,16 @@ __device__ __forceinline__ void sg_set_range(const SgLds &L, const int64_t *__re
     L.range[0] = lo;
     L.range[1] = hi;
     if (batch && n > 0 && b == 0 && c == 0 && (batch[0] < 0 || batch[n - 1] >= B)) report_fault(status, kFaultBatchIndex);
+    // The ranges the bisection finds must tile [0, n): set 0 starts at row 0, set B - 1 ends at row n (a row that no range
+    // covers would never be written by the forward kernel).  Together with the per-point check in the kernels (every row
+    // of a range carries the range's index) this reports what the general path's sort reports: an index outside [0, B)
+    // or out of order ANYWHERE in the vector, not only at its ends.
+    if (batch && n > 0 && c == 0 && ((b == 0 && lo != 0) || (b == B - 1 && hi != n))) report_fault(status, kFaultBatchIndex);
+}
+// row i lies in the range found for set b: its index must be b (c == 0 looks: one load per point and point set)
+__device__ __forceinline__ void sg_check_row(const int64_t *__restrict__ batch, int64_t i, int64_t b, int64_t c, int *__restrict__ status)
+{
+    if (batch && c == 0 && batch[i] != b) report_fault(status, kFaultBatchOrder);
 }
 
 // band index i (0 .. N-1 per axis, row-major over the DIM axes) -> signed frequencies, cube slot and roll-off factor
@@ -197,6 +207,7 @@ small_adjoint_kernel(const int N, const int m, const float *__restrict__ pos, co
     for (int64_t e = threadIdx.x; e < items; e += kSgThreads) {
         const int64_t i = lo + e / rows;
         const int row = (int)(e % rows);
+        if (row == 0) sg_check_row(batch, i, b, c, status);
         int cell[DIM];
         float frac[DIM];
 #pragma unroll
@@ -297,6 +308,7 @@ small_forward_kernel(const int N, const int m, const float *__restrict__ pos, co
     norm = DIM == 3 ? norm * norm * norm : (DIM == 2 ? norm * norm : norm);
     const int W = 2 * m + 2;
     for (int64_t i = lo + threadIdx.x; i < hi; i += kSgThreads) {
+        sg_check_row(batch, i, b, c, status);
         int cell[DIM];
         float frac[DIM];
 #pragma unroll

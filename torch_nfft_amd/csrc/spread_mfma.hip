@@ -207,7 +207,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
         if (mx > 1.0e-30f && mx < 3.0e38f) {  // (tinier inputs: 1 / scale would overflow; their taps flush to zero anyway)
             int e;
             frexpf(mx, &e);
-            xscale = ldexpf(1.0f, e);
+            xscale = ldexpf(1.0f, e > 127 ? 127 : e);  // (|x| in [2^127, 3e38): 2^128 is not a float; 1 / it would be 0)
         }
     }
     // (wave-uniform: keep the scales in scalar registers -- the kernel sits at its 128-VGPR limit)
@@ -652,11 +652,13 @@ extern "C" int nfft_dbg_set_step_trace(void *device_buffer)  // 16 workgroups x 
 constexpr int kAbsmaxThreads = 1024;
 __global__ void __launch_bounds__(kAbsmaxThreads)
 plane_absmax_kernel(const int *__restrict__ tile_offsets, const int64_t bins_per_set, const float *__restrict__ xr,
-                    const int Cr, unsigned *__restrict__ xmax)
+                    const int Cr, const int64_t B, unsigned *__restrict__ xmax)
 {
     __shared__ unsigned lmax[kAbsmaxThreads];
     constexpr int NT = kAbsmaxThreads;
-    const int b = blockIdx.y;
+    // (the y grid holds at most 65 535 point sets: the workgroups stride over the rest)
+    for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
+    if (b != (int64_t)blockIdx.y) __syncthreads();  // lmax is reused
     const int64_t e0 = (int64_t)tile_offsets[b * bins_per_set] * Cr, e1 = (int64_t)tile_offsets[(b + 1) * bins_per_set] * Cr;
     const int64_t chunk = (e1 - e0 + gridDim.x - 1) / gridDim.x;
     const int64_t lo = e0 + chunk * blockIdx.x, hi = min(e1, lo + chunk);
@@ -667,7 +669,7 @@ plane_absmax_kernel(const int *__restrict__ tile_offsets, const int64_t bins_per
             unsigned *const dst = &xmax[(int64_t)b * Cr + (int)(e % Cr)];
             if (v > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, v);
         }
-        return;
+        continue;
     }
     lmax[threadIdx.x] = 0u;
     __syncthreads();
@@ -700,6 +702,7 @@ plane_absmax_kernel(const int *__restrict__ tile_offsets, const int64_t bins_per
         unsigned *const dst = &xmax[(int64_t)b * Cr + threadIdx.x];
         if (lmax[threadIdx.x] > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, lmax[threadIdx.x]);
     }
+    }  // point sets
 }
 
 int launch_plane_absmax(const Geom &g_halo, const PlanLayout &L_halo, const void *plan_halo, const float *xr, int64_t n,
@@ -711,8 +714,8 @@ int launch_plane_absmax(const Geom &g_halo, const PlanLayout &L_halo, const void
     const int *to = (const int *)((const char *)plan_halo + L_halo.off_offsets);
     int64_t blocks = (n * Cr / B + kAbsmaxThreads * 32 - 1) / (kAbsmaxThreads * 32);  // ~32 elements per thread
     blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
-    hipLaunchKernelGGL(plane_absmax_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(kAbsmaxThreads), 0, stream, to,
-                       (int64_t)g_halo.tiles_per_batch * g_halo.SB, xr, (int)Cr, xmax);
+    hipLaunchKernelGGL(plane_absmax_kernel, dim3((unsigned)blocks, (unsigned)(B < 65535 ? B : 65535)), dim3(kAbsmaxThreads), 0, stream, to,
+                       (int64_t)g_halo.tiles_per_batch * g_halo.SB, xr, (int)Cr, B, xmax);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -7,7 +7,12 @@ core_cuda.cu:216, 264), and ``batch`` is sorted (docs/source/theory/dataformat.r
 of the point sets [b0, b1) are one contiguous row range of ``pos`` / ``x``.  There is no halo and no
 reduction; the only exchange is an optional all-gather of the per-rank results when the caller wants
 the full result on every rank (``gather=True``).  A call with a single point set is not split (that
-would need a distributed FFT): it runs on the rank that owns batch 0.
+would need a distributed FFT): it runs on the rank that owns point set 0 (the last one, ``batch_range``).
+
+Two input contracts.  Replicated (default): ``x``, ``pos``, ``batch`` describe the WHOLE batch on every rank and each rank
+picks its row range.  Shard-local (``inputs_are_local=True``): every rank passes only ITS point sets -- what a data-parallel
+caller has -- with ``batch`` numbering them from 0; the layout of the whole call (point sets and points per rank) is
+exchanged by one small all-gather of two counts, and only when a gathered result is asked for.
 
 Rank r of R takes the point sets [floor(r B / R), floor((r+1) B / R)).  ``shard_adjoint`` / ``shard_forward``
 compute one rank's share given (rank, world) explicitly -- the sharded calls are these plus the all-gather, and
@@ -28,7 +33,9 @@ def _layout(batch, world, n, batch_size=None):
     """``(B, bounds, last_sets)``: see shard_layout; ``last_sets[r]`` = index of the last non-empty point set among
     rank r's points (what the forward transform of a shard needs to size its slab).  One read-back for everything."""
     if batch is None:
-        return 1, [0] + [n] * world, [0] * world  # a single point set lives on rank 0
+        # a single point set: its points live on the rank that owns point set 0 -- the LAST one (batch_range(1, r, world)
+        # is (0, 1) for r = world - 1 and empty for every other rank)
+        return 1, [0] * world + [n], [0] * world
     bc = batch.contiguous()
     if batch_size is None:
         B_t = bc[-1:] + 1
@@ -141,12 +148,55 @@ def _world(group):
     return 0, 1
 
 
+def _local_counts(n_sets, n_points, device, group):
+    """(point sets, points) of every rank: one all-gather of two integers per rank."""
+    rank, world = _world(group)
+    if world == 1:
+        return [n_sets], [n_points]
+    mine = torch.tensor([n_sets, n_points], dtype=torch.int64, device=device)
+    allc = torch.empty((2 * world,), dtype=torch.int64, device=device)  # (flat: gloo takes no other output shape)
+    dist.all_gather_into_tensor(allc, mine, group=group)
+    allc = allc.view(world, 2).tolist()
+    return [int(c[0]) for c in allc], [int(c[1]) for c in allc]
+
+
+def _local_sets(batch, n, local_batch_size):
+    """Number of point sets of a shard-local call: given, or ``batch[-1] + 1`` (one blocking read), 1 without a batch
+    vector, 0 for a rank without points."""
+    if local_batch_size is not None:
+        return int(local_batch_size)
+    if n == 0:
+        return 0
+    return 1 if batch is None else int(batch[-1].item()) + 1
+
+
 def nfft_adjoint(x, pos, batch=None, bandwidth=16, cutoff=3, real_output=False, group=None, gather=True,
-                 local_op=None):
+                 local_op=None, inputs_are_local=False, local_batch_size=None):
     """Sharded ``nfft_adjoint``.  ``x``, ``pos``, ``batch`` describe the WHOLE batch and are present on every
     rank; each rank transforms its own point sets.  Returns the full ``[B, N.., *cols]`` spectrum on every
-    rank (``gather=True``, one all-gather along dim 0) or this rank's ``[B_r, N.., *cols]`` slab."""
+    rank (``gather=True``, one all-gather along dim 0) or this rank's ``[B_r, N.., *cols]`` slab.
+
+    ``inputs_are_local=True``: ``x``, ``pos``, ``batch`` hold THIS rank's point sets only (``batch`` counts them from 0;
+    ``local_batch_size`` states their number when the last ones may be empty).  The slab of rank r follows those of the
+    ranks before it in the gathered spectrum."""
     rank, world = _world(group)
+    if inputs_are_local:
+        op = local_op or _nfft.nfft_adjoint
+        n_r = pos.shape[0]
+        B_r = _local_sets(batch, n_r, local_batch_size)
+        if n_r > 0:
+            y = op(x, pos, batch, bandwidth=bandwidth, cutoff=cutoff, real_output=real_output)
+            if y.shape[0] != B_r:  # trailing empty point sets
+                pad = y.new_zeros((B_r,) + tuple(y.shape[1:]))
+                pad[:y.shape[0]] = y
+                y = pad
+        else:
+            y = x.new_zeros((B_r,) + (bandwidth,) * pos.shape[1] + tuple(x.shape[1:]),
+                            dtype=torch.float32 if real_output else torch.complex64)
+        if not gather or world == 1:
+            return y
+        sets, _ = _local_counts(B_r, n_r, y.device, group)
+        return _all_gather_rows(y, sets, group)
     B, bounds = shard_layout(batch, world, pos.shape[0])
     y = shard_adjoint(x, pos, batch, B, rank, world, bandwidth, cutoff, real_output, local_op, bounds)
     if not gather or world == 1:
@@ -156,13 +206,30 @@ def nfft_adjoint(x, pos, batch=None, bandwidth=16, cutoff=3, real_output=False, 
 
 
 def nfft_forward(x, pos, batch=None, cutoff=3, real_output=False, group=None, gather=True, local_op=None,
-                 x_is_local=False):
+                 x_is_local=False, inputs_are_local=False):
     """Sharded ``nfft_forward``.  ``x`` is the full ``[B, N.., *cols]`` spectrum (each rank only reads its own
     slab) or, with ``x_is_local=True``, this rank's slab ``[B_r, N.., *cols]`` -- the output of
     ``nfft_adjoint(..., gather=False)``, so an adjoint -> (spectral work) -> forward pipeline never replicates the
     spectra (34.4 GB per rank at C4).  Returns all ``[n, *cols]`` rows on every rank (``gather=True``) or this rank's
-    rows."""
+    rows.
+
+    ``inputs_are_local=True``: ``pos``, ``batch`` hold this rank's points only (``batch`` counts its point sets from 0) and
+    ``x`` is its slab ``[B_r, N.., *cols]``; the gathered result lists the ranks' rows one rank after the other."""
     rank, world = _world(group)
+    if inputs_are_local:
+        op = local_op or _nfft.nfft_forward
+        n_r, d = pos.shape[0], pos.shape[1]
+        if n_r > 0:
+            nb = 1 if batch is None else int(batch[-1].item()) + 1
+            if x.shape[0] < nb:
+                raise RuntimeError("Input mismatch")
+            y = op(x[:nb], pos, batch, cutoff=cutoff, real_output=real_output)
+        else:
+            y = x.new_zeros((0,) + tuple(x.shape[1 + d:]), dtype=torch.float32 if real_output else torch.complex64)
+        if not gather or world == 1:
+            return y
+        _, points = _local_counts(x.shape[0], n_r, y.device, group)
+        return _all_gather_rows(y, points, group)
     B, bounds, lasts = _layout(batch, world, pos.shape[0])
     b0, b1 = batch_range(B, rank, world)
     if x.shape[0] != (b1 - b0 if x_is_local else B):

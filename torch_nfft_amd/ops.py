@@ -11,9 +11,11 @@ Point-plan reuse.  The tile-sorted copy of the points d
 ``(pos, batch, N, m)``; adjoint <-> forward pairs on the same points (autograd backward, a forward fed by an
 adjoint, fastsum) reuse it instead of re-binning.  The cache lives in ``core.so``: two entries, keyed on tensor
 identity + version counter, stream-aware (a plan built on one stream is waited for and recorded on the consuming
-stream).  LIMITATION: writes that bypass the version counter -- ``pos.data.copy_()``, kernels of other libraries,
-DLPack aliases -- are invisible to it; code that edits points that way calls ``plan_cache_clear()`` afterwards or
-``plan_cache_enabled(False)`` once.  The same switches govern the remembered ENDS of the batch vector
+stream).  Writes that bypass the version counter -- ``pos.data.copy_()``, kernels of other libraries, DLPack aliases --
+are invisible to the KEY, so every plan that enters the cache is sealed with a checksum of ``pos`` / ``batch`` and every hit
+re-checks it (one streaming pass, ~25 us for 10^7 points): a stale plan raises "stale point plan" at the next operator or
+``check_status()`` instead of returning a transform of points that are no longer there (``plan_cache_verify(False)`` for
+callers who never write that way).  The same switches govern the remembered ENDS of the batch vector
 (``B = batch[-1] + 1`` otherwise costs a blocking read-back of ~35 us in every operator call, as in the reference's
 ``check_point_input``, core_cuda.cu:60): same key (identity + version counter), same limitation.
 """
@@ -28,6 +30,11 @@ def plan_cache_enabled(flag):
 
 def plan_cache_clear():
     _ops._plan_cache(0)
+
+
+def plan_cache_verify(flag):
+    """Seal plans that enter the cache and verify the seal on every hit (default on)."""
+    _ops._plan_cache(5 if flag else 6)
 
 
 def plan_cache_stats():
