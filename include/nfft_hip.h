@@ -126,14 +126,14 @@ int64_t nfft_hip_plan_bytes(const nfft_hip_problem *p);
 int nfft_hip_plan_points(const nfft_hip_problem *p, const float *pos, const int64_t *batch,
                          void *plan, int64_t plan_bytes, void *stream);
 
-/* Seal and verification of a plan that is kept across calls.  nfft_hip_plan_seal stores a 64-bit checksum of pos (and
- * batch) in the plan; nfft_hip_plan_verify recomputes it from the arrays as they are NOW (one streaming pass, ~25 us for
- * 10^7 3-D points) and raises a device fault when it differs: the next entry point on the device returns
- * NFFT_HIP_EINVAL ("stale point plan"), nfft_hip_check_status sees it on demand.  A cache of plans keyed on buffer
- * identity (core.so's: tensor address + version counter) cannot see a write that bypasses its key; the reference has no
- * such state -- it recomputes shifts and psi in every call (csrc/cuda/core_cuda.cu:188-211) -- so a drop-in must not
- * return a transform of points that are no longer there without saying so. */
-int nfft_hip_plan_seal(const nfft_hip_problem *p, const float *pos, const int64_t *batch, void *plan, void *stream);
+/* Verification of a plan that is kept across calls.  nfft_hip_plan_points leaves a 64-bit checksum of pos (and batch) in
+ * the plan -- its seal, formed by the pass that counts the points, at no extra cost; nfft_hip_plan_verify recomputes it
+ * from the arrays as they are NOW (one streaming pass, ~25 us for 10^7 3-D points) and raises a device fault when it
+ * differs: the next entry point on the device returns NFFT_HIP_EINVAL ("stale point plan"), nfft_hip_check_status sees
+ * it on demand.  A cache of plans keyed on buffer identity (core.so's: tensor address + version counter) cannot see a
+ * write that bypasses its key; the reference has no such state -- it recomputes shifts and psi in every call
+ * (csrc/cuda/core_cuda.cu:188-211) -- so a drop-in must not return a transform of points that are no longer there
+ * without saying so. */
 int nfft_hip_plan_verify(const nfft_hip_problem *p, const float *pos, const int64_t *batch, void *plan, void *stream);
 
 /* Spreading (adjoint gridding):  grid[(b*Cr + cr), u] += xr[i, cr] * prod_k psi_k(i, u_k)

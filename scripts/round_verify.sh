@@ -7,5 +7,5 @@ O=gpurun_out
 timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $O/verify_tests.log 2>&1
 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/verify_smoke.log 2>&1
 bash scripts/profile_round.sh > $O/verify_profile.log 2>&1
-cp $O/r3p_spread_traffic.json profiles/r03_spread_traffic.json
+cp $O/r4p_spread_traffic.json profiles/r04_spread_traffic.json
 timeout -k 10 900 python3 bench.py > $O/verify_bench.json 2> $O/verify_bench.err

@@ -571,6 +571,6 @@ def test_shard_local_inputs_world1(tn):
     ya = tnd.nfft_adjoint(x, pos, batch, bandwidth=N, cutoff=m, inputs_are_local=True, local_batch_size=4)
     ref = tn.nfft_adjoint(x, pos, batch, bandwidth=N, cutoff=m)
     assert ya.shape[0] == 4 and float(ya[3].abs().max()) == 0.0          # a trailing empty point set
-    assert torch.equal(ya[:3], ref)
+    assert rel_l2(host(ya[:3]), host(ref)) < 1e-6                        # (float atomics: not bit for bit)
     yf = tnd.nfft_forward(ya, pos, batch, cutoff=m, real_output=True, inputs_are_local=True)
-    assert torch.equal(yf, tn.nfft_forward(ref, pos, batch, cutoff=m, real_output=True))
+    assert rel_l2(host(yf), host(tn.nfft_forward(ya[:3], pos, batch, cutoff=m, real_output=True))) < 1e-6

@@ -557,7 +557,7 @@ def test_dynamic_range_inside_one_column():
     gen = torch.Generator(device="cuda").manual_seed(3)
     pos = torch.rand((n, 3), generator=gen, device="cuda") - 0.5
     x = torch.rand((n,), generator=gen, device="cuda") + 0.5
-    small = pos[:, 0] > 0.0                      # half of the torus along axis 0 carries coefficients 10^6 times smaller
+    small = pos[:, 0] < 0.0                      # half of the torus along axis 0 (cells [M/2, M)) carries coefficients 10^6 times smaller
     x = torch.where(small, x * 1e-6, x).contiguous()
     prob = _lib.Problem(3, n, 1, 1, N, m)
     p = lambda t: ctypes.c_void_p(t.data_ptr())

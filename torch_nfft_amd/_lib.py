@@ -28,7 +28,6 @@ SYMBOLS = (
     "nfft_hip_forward_planned",
     "nfft_hip_plan_bytes",
     "nfft_hip_plan_points",
-    "nfft_hip_plan_seal",
     "nfft_hip_plan_verify",
     "nfft_hip_spread_scratch_bytes",
     "nfft_hip_spread",
@@ -113,8 +112,6 @@ def load():
     lib.nfft_hip_spread_scratch_bytes.restype = i64
     lib.nfft_hip_spread.argtypes = [P, vp, vp, i64, vp, vp, vp]
     lib.nfft_hip_spread.restype = ci
-    lib.nfft_hip_plan_seal.argtypes = [P, vp, vp, vp, vp]
-    lib.nfft_hip_plan_seal.restype = ci
     lib.nfft_hip_plan_verify.argtypes = [P, vp, vp, vp, vp]
     lib.nfft_hip_plan_verify.restype = ci
     lib.nfft_hip_interpolate.argtypes = [P, vp, vp, i64, vp, vp]

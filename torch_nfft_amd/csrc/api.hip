@@ -264,7 +264,7 @@ struct PlanSet {
     bool owned;
     Geom go;
     PlanLayout Lo;
-    int64_t off_own, off_seal, total;  // off_seal: the plan's seal (kernels.h), behind the sorted points
+    int64_t off_own, total;
     const Geom &spread_geom() const { return owned ? go : g; }
     const PlanLayout &spread_layout() const { return owned ? Lo : L; }
     const void *spread_plan(const void *plan) const { return owned ? (const char *)plan + off_own : (const char *)plan; }
@@ -294,8 +294,6 @@ PlanSet plan_set(const nfft_hip_problem *p)
         ps.off_own = align_up(ps.L.total, 256);
         ps.total = ps.off_own + ps.Lo.total;
     }
-    ps.off_seal = align_up(ps.total, 256);
-    ps.total = ps.off_seal + kSealBytes;
     return ps;
 }
 int build_plans(const PlanSet &ps, const float *pos, const int64_t *batch, int64_t n, int64_t B, void *plan, hipStream_t s)
@@ -559,19 +557,12 @@ int nfft_hip_plan_points(const nfft_hip_problem *p, const float *pos, const int6
     return build_plans(ps, pos, batch, p->num_points, p->batch_size, plan, (hipStream_t)stream);
 }
 
-int nfft_hip_plan_seal(const nfft_hip_problem *p, const float *pos, const int64_t *batch, void *plan, void *stream)
-{
-    if (int rc = validate(p)) return rc;
-    if (!plan || (p->num_points > 0 && !pos)) { set_error("Input mismatch: null plan or pos"); return NFFT_HIP_EINVAL; }
-    return launch_points_seal(pos, batch, p->num_points, p->dim, (char *)plan + plan_set(p).off_seal, (hipStream_t)stream);
-}
-
 int nfft_hip_plan_verify(const nfft_hip_problem *p, const float *pos, const int64_t *batch, void *plan, void *stream)
 {
     if (int rc = validate(p)) return rc;
     if (!plan || (p->num_points > 0 && !pos)) { set_error("Input mismatch: null plan or pos"); return NFFT_HIP_EINVAL; }
     static std::atomic<unsigned> slot{0};  // eight verifications of one plan may be in flight (on different streams)
-    return launch_points_verify(pos, batch, p->num_points, p->dim, (char *)plan + plan_set(p).off_seal, (int)(slot++ & 7u),
+    return launch_points_verify(pos, batch, p->num_points, p->dim, (char *)plan + plan_set(p).L.off_seal, (int)(slot++ & 7u),
                                 (hipStream_t)stream);
 }
 

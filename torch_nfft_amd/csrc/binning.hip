@@ -41,6 +41,7 @@ PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)
     int64_t o = 0;
     L.off_offsets = o; o = align_up(o + (L.ntiles + 1) * 4, 256);
     L.off_cursor = o;  o = align_up(o + (L.ntiles + 1) * 4, 256);
+    L.off_seal = o;    o += kSealBytes;  // the plan's seal (kernels.h), right behind the cursors: one memset zeroes both
     L.off_perm = o;    o = align_up(o + (g.dim == 3 ? 0 : L.cap * 4), 256);  // (3-D: the index sits in the record)
     L.off_spos = o;    o = align_up(o + L.cap * g.pstride * 4, 256);
     L.off_scan = o;    o = align_up(o + L.scan_bytes, 256);
@@ -59,6 +60,7 @@ PlanLayout plan_layout(const Geom &g, int64_t n, int64_t B)
     L.off_work = o;    o = align_up(o + (g.wide ? (L.work_head + 2 * L.work_cap) * 16 : 0), 256);
     // the count passes leave the keys they computed for the scatter passes (two bytes per point / record instead of
     // two or three more split_cell + tile-index evaluations)
+    L.off_sealpart = o; o = align_up(o + (L.two_level ? L.nblocks * 8 : 0), 256);  // per-slice shares of the seal (count pass)
     L.off_key1 = o;    o = align_up(o + (L.two_level && !g.owned ? n * 2 : 0), 256);
     L.off_key2 = o;    o = align_up(o + (L.two_level ? L.cap * 2 : 0), 256);
     L.total = o;
@@ -86,16 +88,54 @@ __device__ __forceinline__ int point_tiles(const Geom &g, const float *__restric
     return 1;
 }
 
+// ---- seal of a plan: checksum of the data it was built from -------------------------------------------------------------
+// A plan cached across calls is keyed on tensor identity + version counter; a write that bypasses the counter (pos.data,
+// a foreign kernel, a DLPack alias) would make the cached plan silently wrong -- the reference recomputes shifts and psi
+// in every call (core_cuda.cu:188-211) and has no such state.  Every point enters an order-independent 64-bit sum with a
+// 32-bit hash of its words and its index (bijective in every word: a changed word always changes the point's hash, two
+// changes cancel with probability 2^-32).  The count passes of the sort form it on the side -- ~14 integer operations per
+// point; a first version with one avalanche per WORD made the instruction-bound count pass 18 % slower -- and the
+// verification of a cached plan recomputes it in one streaming pass (~25 us for 10^7 3-D points).
+constexpr int kSealThreads = 256;
+__device__ __forceinline__ unsigned long long seal_point(int dim, int64_t i, float c0, float c1, float c2, bool has_batch, int64_t b)
+{
+    unsigned h = __float_as_uint(c0) * 0x9E3779B1u + (unsigned)i * 0x85EBCA77u + (unsigned)((unsigned long long)i >> 32) * 0x27D4EB2Fu;
+    if (dim > 1) h += __float_as_uint(c1) * 0xC2B2AE3Du;
+    if (dim > 2) h += __float_as_uint(c2) * 0x165667B1u;
+    if (has_batch) h += (unsigned)b * 0x7FEB352Du + (unsigned)((unsigned long long)b >> 32) * 0x846CA68Bu;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    return (unsigned long long)h;
+}
+// sum over the workgroup (256 .. 1024 threads), valid in thread 0
+__device__ __forceinline__ unsigned long long seal_block_sum(unsigned long long sum, unsigned long long *part /* LDS, 16 words */)
+{
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    unsigned long long s = 0;
+    if (threadIdx.x == 0)
+        for (unsigned i = 0; i < (blockDim.x + 63) / 64; ++i) s += part[i];
+    return s;
+}
+
 __global__ void __launch_bounds__(256) bin_count_kernel(Geom g, const float *__restrict__ pos,
                                                        const int64_t *__restrict__ batch, int64_t n, int64_t B,
-                                                       int *__restrict__ count, int *__restrict__ status)
+                                                       int *__restrict__ count, unsigned long long *__restrict__ seal,
+                                                       int *__restrict__ status)
 {
+    __shared__ unsigned long long part[16];
+    unsigned long long sum = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         if (batch && (batch[i] < 0 || batch[i] >= B)) report_fault(status, kFaultBatchIndex);  // (binned clamped; the next call fails)
         int tiles[4];
         const int k = point_tiles(g, pos, batch, i, B, tiles);
         for (int q = 0; q < k; ++q) atomicAdd(&count[tiles[q]], 1);
+        // the plan's seal (checksum of the points it is built from): this pass reads every word of pos / batch anyway
+        sum += seal_point(g.dim, i, pos[i * g.dim], g.dim > 1 ? pos[i * g.dim + 1] : 0.f, g.dim > 2 ? pos[i * g.dim + 2] : 0.f,
+                          batch != nullptr, batch ? batch[i] : 0);
     }
+    sum = seal_block_sum(sum, part);
+    if (threadIdx.x == 0 && sum) atomicAdd(seal, sum);
 }
 
 __global__ void __launch_bounds__(256) bin_fill_kernel(Geom g, const float *__restrict__ pos,
@@ -184,6 +224,7 @@ __global__ void __launch_bounds__(kSortThreads)
 sort1_count_kernel(Geom g_in, const float *__restrict__ pos, const int64_t *__restrict__ batch, int64_t n, int64_t B,
                    int npencils, int nblocks, int block_points, int *__restrict__ hist /* [pencil][block] */,
                    unsigned short *__restrict__ key1 /* first-level bin of every point (not for the owned tiling) */,
+                   unsigned long long *__restrict__ seal_part /* [block]: the slice's share of the plan's seal, or null */,
                    int *__restrict__ status)
 {
     // COMMON: a 3-D problem on the scatter tiling (every benchmark configuration): with the two flags constant the
@@ -196,6 +237,7 @@ sort1_count_kernel(Geom g_in, const float *__restrict__ pos, const int64_t *__re
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * block_points;
     const int64_t hi = min(n, lo + block_points);
+    unsigned long long seal = 0;  // the plan's seal (a checksum of pos / batch, kernels.h): this pass reads every word anyway
     for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)kSortThreads * kSortUnroll) {
         float c0[kSortUnroll], c1[kSortUnroll], c2[kSortUnroll];
         int64_t bb[kSortUnroll];
@@ -209,6 +251,7 @@ sort1_count_kernel(Geom g_in, const float *__restrict__ pos, const int64_t *__re
 #pragma unroll
         for (int q = 0; q < kSortUnroll; ++q) {
             if (i0 + (int64_t)q * kSortThreads >= hi) continue;
+            if (seal_part) seal += seal_point(g.dim, i0 + (int64_t)q * kSortThreads, c0[q], c1[q], c2[q], batch != nullptr, bb[q]);
             // (the host layer reads the first and the last entry only: an index outside [0, B) in between is binned
             // clamped, keeps every access in range, and is reported -- the next entry point fails with "Input mismatch")
             if (bb[q] < 0 || bb[q] >= B) report_fault(status, kFaultBatchIndex);
@@ -221,14 +264,30 @@ sort1_count_kernel(Geom g_in, const float *__restrict__ pos, const int64_t *__re
     }
     __syncthreads();
     for (int i = threadIdx.x; i < npencils; i += kSortThreads) hist[(int64_t)i * nblocks + blockIdx.x] = lds_hist[i];
+    if (seal_part) {
+        __shared__ unsigned long long part[16];
+        seal = seal_block_sum(seal, part);
+        if (threadIdx.x == 0) seal_part[blockIdx.x] = seal;
+    }
 }
 
 template <bool COMMON>
 __global__ void __launch_bounds__(kSortThreads)
 sort1_scatter_kernel(Geom g_in, const float *__restrict__ pos, const int64_t *__restrict__ batch, int64_t n, int64_t B,
                      int npencils, int nblocks, int block_points, const int *__restrict__ hscan, const unsigned short *__restrict__ key1,
-                     float4 *__restrict__ tmp)
+                     float4 *__restrict__ tmp, const unsigned long long *__restrict__ seal_part, unsigned long long *__restrict__ seal)
 {
+    if (seal && blockIdx.x == 0) {
+        // the plan's seal: sum of the count pass's per-slice shares; the rest of the seal block (accumulators and arrival
+        // counters of verifications) starts at zero
+        __shared__ unsigned long long part[16];
+        unsigned long long sum = 0;
+        for (int i = threadIdx.x; i < nblocks; i += kSortThreads) sum += seal_part[i];
+        sum = seal_block_sum(sum, part);
+        if (threadIdx.x == 0) seal[0] = sum;
+        if (threadIdx.x >= 1 && threadIdx.x < (int)(kSealBytes / 8)) seal[threadIdx.x] = 0ull;
+        __syncthreads();
+    }
     // COMMON: a 3-D problem on the scatter tiling (every benchmark configuration): with the two flags constant the
     // per-point paths lose their run-time branches on dimension and tiling (8-fold unrolled: 43 KB of code per kernel
     // before), the instruction-bound count passes most of all
@@ -650,6 +709,8 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
     int *cursor = (int *)(base + L.off_cursor);
     int *perm = (int *)(base + L.off_perm);
     float *spos = (float *)(base + L.off_spos);
+    // every plan is sealed by the pass that counts its points (kernels.h: kSealBytes)
+    unsigned long long *const seal = (unsigned long long *)(base + L.off_seal);
     if (L.two_level) {
         int *hist = (int *)(base + L.off_hist);
         int *hscan = (int *)(base + L.off_hscan);
@@ -660,13 +721,14 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
         unsigned short *key1 = (unsigned short *)(base + L.off_key1), *key2 = (unsigned short *)(base + L.off_key2);
         const bool common = g.dim == 3 && !g.owned;
         hipLaunchKernelGGL(common ? sort1_count_kernel<true> : sort1_count_kernel<false>, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
-                           npencils, nblocks, (int)L.block_points, hist, key1, device_status_block());
+                           npencils, nblocks, (int)L.block_points, hist, key1, seal ? (unsigned long long *)(base + L.off_sealpart) : nullptr,
+                           device_status_block());
         size_t scan_bytes = 0;
         NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, hist, hscan, (int)items, stream));
         if ((int64_t)scan_bytes > L.scan_bytes) { set_error("scan scratch too small"); return 2; }
         NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(base + L.off_scan, scan_bytes, hist, hscan, (int)items, stream));
         hipLaunchKernelGGL(common ? sort1_scatter_kernel<true> : sort1_scatter_kernel<false>, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
-                           npencils, nblocks, (int)L.block_points, hscan, key1, tmp);
+                           npencils, nblocks, (int)L.block_points, hscan, key1, tmp, (const unsigned long long *)(base + L.off_sealpart), seal);
         int *hist2 = (int *)(base + L.off_hist2);
         const size_t lds2 = (size_t)g.l1bins * g.SB * g.CG * 4;
         hipLaunchKernelGGL(common ? sort2_count_kernel<true> : sort2_count_kernel<false>, dim3(npencils, kSort2Parts), dim3(kSortThreads), lds2, stream, g, nblocks,
@@ -677,11 +739,13 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
         NFFT_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    // counts are accumulated in `cursor`, scanned into `offsets`, then `cursor` restarts at zero
-    NFFT_HIP_CHECK(hipMemsetAsync(cursor, 0, (L.ntiles + 1) * 4, stream));
+    // counts are accumulated in `cursor`, scanned into `offsets`, then `cursor` restarts at zero (the plan's seal block lies
+    // right behind `cursor`: the same memset zeroes it, the count pass adds the checksum of the points to it)
+    static_assert(kSealBytes == 256, "the seal block fills one alignment unit behind the cursors");
+    NFFT_HIP_CHECK(hipMemsetAsync(cursor, 0, (size_t)(L.off_seal + kSealBytes - L.off_cursor), stream));
     if (n > 0) {
         hipLaunchKernelGGL(bin_count_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, g, pos, batch, n, B, cursor,
-                           device_status_block());
+                           (unsigned long long *)(base + L.off_seal), device_status_block());
     }
     size_t scan_bytes = 0;
     NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, cursor, offsets, (int)(L.ntiles + 1), stream));
@@ -698,48 +762,21 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
     return 0;
 }
 
-// ---- seal of a plan: checksum of the data it was built from -------------------------------------------------------------
-// A plan cached across calls is keyed on tensor identity + version counter; a write that bypasses the counter (pos.data,
-// a foreign kernel, a DLPack alias) would make the cached plan silently wrong -- the reference recomputes shifts and psi
-// in every call (core_cuda.cu:188-211) and has no such state.  Every word of pos (and batch) enters an order-independent
-// 64-bit sum of per-word hashes (word index mixed in): one streaming pass with 16-byte loads, ~25 us for 10^7 3-D points.
-constexpr int kSealThreads = 256;
-__device__ __forceinline__ unsigned long long seal_word(unsigned w, unsigned long long idx, unsigned seed)
-{
-    unsigned h = (w ^ seed) + (unsigned)idx * 0x9E3779B1u + (unsigned)(idx >> 32) * 0x85EBCA77u;
-    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
-    return (unsigned long long)h | ((unsigned long long)(h * 0xC2B2AE3Du) << 32);
-}
-__device__ __forceinline__ unsigned long long seal_range(const unsigned *__restrict__ w, int64_t words, unsigned seed)
-{
-    unsigned long long sum = 0;
-    const int64_t stride = (int64_t)gridDim.x * kSealThreads;
-    const int64_t t = (int64_t)blockIdx.x * kSealThreads + threadIdx.x;
-    const int64_t quads = ((uintptr_t)w & 15) == 0 ? words / 4 : 0;  // (torch allocations are 16-byte aligned)
-    const uint4 *w4 = (const uint4 *)w;
-    for (int64_t q = t; q < quads; q += stride) {
-        const uint4 v = w4[q];
-        sum += seal_word(v.x, 4 * q, seed) + seal_word(v.y, 4 * q + 1, seed) + seal_word(v.z, 4 * q + 2, seed) +
-               seal_word(v.w, 4 * q + 3, seed);
-    }
-    for (int64_t i = 4 * quads + t; i < words; i += stride) sum += seal_word(w[i], i, seed);
-    return sum;
-}
 __global__ void __launch_bounds__(kSealThreads)
-points_seal_kernel(const unsigned *__restrict__ pos_words, int64_t npos, const unsigned *__restrict__ batch_words, int64_t nbatch,
+points_seal_kernel(const float *__restrict__ pos, const int64_t *__restrict__ batch, int64_t n, int dim,
                    unsigned long long *__restrict__ acc, const unsigned long long *__restrict__ expect,
                    unsigned *__restrict__ arrivals, int *__restrict__ status)
 {
-    unsigned long long sum = seal_range(pos_words, npos, 0x243F6A88u);
-    if (batch_words) sum += seal_range(batch_words, nbatch, 0x13198A2Eu);
-    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
-    __shared__ unsigned long long part[kSealThreads / 64];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
-    __syncthreads();
+    unsigned long long sum = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kSealThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kSealThreads) {
+        float c0, c1, c2;
+        load_point(pos, dim, i, true, c0, c1, c2);
+        sum += seal_point(dim, i, c0, c1, c2, batch != nullptr, batch ? batch[i] : 0);
+    }
+    __shared__ unsigned long long part[16];
+    sum = seal_block_sum(sum, part);
     if (threadIdx.x == 0) {
-        unsigned long long s = 0;
-        for (int i = 0; i < kSealThreads / 64; ++i) s += part[i];
-        atomicAdd(acc, s);
+        if (sum) atomicAdd(acc, sum);
         if (expect) {
             // verification: the last workgroup to arrive compares the finished sum with the plan's seal
             __threadfence();
@@ -755,19 +792,12 @@ points_seal_kernel(const unsigned *__restrict__ pos_words, int64_t npos, const u
 static int seal_launch(const float *pos, const int64_t *batch, int64_t n, int dim, unsigned long long *acc,
                        const unsigned long long *expect, unsigned *arrivals, hipStream_t stream)
 {
-    const int64_t npos = n * dim, nbatch = batch ? 2 * n : 0;
-    int64_t blocks = (npos + nbatch + kSealThreads * 64 - 1) / (kSealThreads * 64);  // ~64 words per thread
-    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-    hipLaunchKernelGGL(points_seal_kernel, dim3((unsigned)blocks), dim3(kSealThreads), 0, stream, (const unsigned *)pos, npos,
-                       (const unsigned *)batch, nbatch, acc, expect, arrivals, device_status_block());
+    int64_t blocks = (n + kSealThreads * 16 - 1) / (kSealThreads * 16);  // ~16 points per thread
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(points_seal_kernel, dim3((unsigned)blocks), dim3(kSealThreads), 0, stream, pos, batch, n, dim, acc, expect,
+                       arrivals, device_status_block());
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
-}
-
-int launch_points_seal(const float *pos, const int64_t *batch, int64_t n, int dim, void *seal, hipStream_t stream)
-{
-    NFFT_HIP_CHECK(hipMemsetAsync(seal, 0, (size_t)kSealBytes, stream));
-    return seal_launch(pos, batch, n, dim, (unsigned long long *)seal, nullptr, nullptr, stream);
 }
 
 int launch_points_verify(const float *pos, const int64_t *batch, int64_t n, int dim, void *seal, int slot, hipStream_t stream)

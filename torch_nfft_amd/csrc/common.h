@@ -430,12 +430,14 @@ struct DeviceOnce {
     void mark();
 };
 
+constexpr int64_t kSealBytes = 256;  // seal block of a plan: [0] checksum, [1 .. 8] verification accumulators, then their counters
 struct PlanLayout {
     int64_t cap;  // entries the plan can hold: n, or 4 n for the owned tiling (an entry per touched tile)
     int64_t ntiles;
     int64_t npencils, nblocks, block_points;  // two-level sort geometry
     bool two_level;
     int64_t off_offsets, off_cursor, off_perm, off_spos, off_scan, scan_bytes;
+    int64_t off_seal, off_sealpart;  // the plan's seal (checksum of pos / batch: kernels.h) and the count pass's partial sums
     int64_t off_hist, off_hscan, off_tmp, off_hist2;
     int64_t off_groups;  // column-group starts (two ints per plan bin) when `grouped`
     int64_t off_work, work_cap, work_head;  // wide tiling: work list {work_head 16-byte words: header + one int2 per point

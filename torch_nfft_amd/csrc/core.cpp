@@ -192,7 +192,7 @@ struct PlanCache {
     std::mutex mutex;
     PlanEntry entries[2];
     bool enabled = true;
-    bool verify = true;  // seal plans that enter the cache and check the seal on every hit (plan_cache_control 5 / 6)
+    bool verify = true;  // check a cached plan's seal on every hit (plan_cache_control 5 / 6)
     int64_t hits = 0, misses = 0;
     uint64_t tick = 0;
     void clear()
@@ -302,7 +302,6 @@ at::Tensor get_plan(const Points &p, const nfft_hip_problem &q)
     int64_t nbytes = 0;
     plan = new_plan_buffer(p, q, nbytes);
     check_rc(nfft_hip_plan_points(&q, pos, batch, plan.data_ptr(), nbytes, lk.stream));
-    if (lk.use_cache && g_cache.verify) check_rc(nfft_hip_plan_seal(&q, pos, batch, plan.data_ptr(), lk.stream));
     cache_insert(lk, p, plan);
     return plan;
 }

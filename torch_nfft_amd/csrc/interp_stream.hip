@@ -64,6 +64,24 @@ struct __align__(16) StreamLds {
     int run_blk[kIsMaxRuns + 4];     // blocks whose first point lies in a run before e (prefix sums); [runs] = all blocks
 };
 
+// Ordering of the LDS hand-overs between producer and consumer waves.  The LDS unit serves the requests of ONE wave in
+// the order they were issued: "data, then flag" on the producer side and "flag, then data" on the consumer side need no
+// wait, only the compiler must keep the program order.  The workgroup-scope fences that stood here until round 4 compile
+// to s_waitcnt vmcnt(0) as well: a consumer then waited at every block for the acknowledgement of its scattered result
+// stores and for the point records of the NEXT block it had just requested (profiles/r04_experiments.md).
+#ifndef NFFT_STREAM_LDS_ORDER
+#define NFFT_STREAM_LDS_ORDER 1
+#endif
+__device__ __forceinline__ void lds_release()
+{
+    if (NFFT_STREAM_LDS_ORDER) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
+__device__ __forceinline__ void lds_acquire()
+{
+    if (NFFT_STREAM_LDS_ORDER) asm volatile("" ::: "memory");
+    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 __device__ __forceinline__ int lds_load(const int *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -261,7 +279,7 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
                 }
                 __builtin_amdgcn_s_sleep(4);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            lds_acquire();
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int t = lane + 64 * i;
@@ -277,7 +295,7 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
                 L.frag[slot][cg >> 1][1][ln] = __builtin_bit_cast(f16x8, u32x4{q0, q1, q2, q3});
             }
             if (lane == 0) L.pinv[slot] = inv * (1.0f / kOpScale);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            lds_release();
             if (lane == 0) lds_store(&L.ready[slot], z);
             if (lds_load(&L.abort)) break;
             // (every consumer gone: nobody reads what is left of the sweep)
@@ -355,7 +373,7 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
             const int z_last = __builtin_amdgcn_readlane(c0, nvalid - 1) + m + 1;
             // planes below z_first are no longer mine: the fragment reads of the previous block must have completed
             // before a producer sees this and overwrites their slots
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            lds_release();
             if (lane == 0) lds_store(&L.progress[wave], z_first);
             const int ks0 = NG == 3 ? grp : 0;  // first k-step of the block's group
 
@@ -416,7 +434,7 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
                     if (lds_load(&L.abort) || ++spins > kSpinLimit) { bail = true; break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                lds_acquire();
             }
             if (bail) {
                 // the host learns of it (nfft_hip_check_status): the rows this item has not written stay undefined
@@ -483,7 +501,7 @@ interp_stream_kernel(const Geom g, const int *__restrict__ tile_offsets, const i
             q0 = n0; q1 = n1; q2 = n2;
         }
         // nothing of the ring is mine any more: the producers may run to the end of their sweep
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        lds_release();
         if (lane == 0) lds_store(&L.progress[wave], INT_MAX);
     }
     }  // work items

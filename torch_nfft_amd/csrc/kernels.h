@@ -8,11 +8,10 @@ namespace nfft {
 // binning.hip
 int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, const int64_t *batch, int64_t n, int64_t B,
                        void *plan, hipStream_t stream);
-// Seal of a point plan: a 64-bit checksum of the points (and the batch vector) it was built from.  `seal` is a 256-byte
-// block: [0] the checksum, [1 .. 8] accumulators of verifications in flight, then their arrival counters.  verify:
-// recompute into accumulator `slot` and raise kFaultStalePlan in the device's status block when it differs.
-constexpr int64_t kSealBytes = 256;
-int launch_points_seal(const float *pos, const int64_t *batch, int64_t n, int dim, void *seal, hipStream_t stream);
+// Seal of a point plan: a 64-bit checksum of the points (and the batch vector) it was built from, left in the plan's seal
+// block (common.h: PlanLayout::off_seal) by the pass that counts the points -- no pass of its own.  verify: recompute the
+// checksum from the arrays as they are now into accumulator `slot` and raise kFaultStalePlan in the device's status
+// block when it differs.
 int launch_points_verify(const float *pos, const int64_t *batch, int64_t n, int dim, void *seal, int slot, hipStream_t stream);
 // xs[c * n + slot] = xr[perm[slot] * cols + c]
 int launch_gather_rows(const Geom &g, const PlanLayout &L, const void *plan, int64_t n, const float *xr, int64_t cols,

@@ -12,7 +12,7 @@ Point-plan reuse.  The tile-sorted copy of the points d
 adjoint, fastsum) reuse it instead of re-binning.  The cache lives in ``core.so``: two entries, keyed on tensor
 identity + version counter, stream-aware (a plan built on one stream is waited for and recorded on the consuming
 stream).  Writes that bypass the version counter -- ``pos.data.copy_()``, kernels of other libraries, DLPack aliases --
-are invisible to the KEY, so every plan that enters the cache is sealed with a checksum of ``pos`` / ``batch`` and every hit
+are invisible to the KEY, so every plan carries a checksum of the ``pos`` / ``batch`` it was built from and every hit
 re-checks it (one streaming pass, ~25 us for 10^7 points): a stale plan raises "stale point plan" at the next operator or
 ``check_status()`` instead of returning a transform of points that are no longer there (``plan_cache_verify(False)`` for
 callers who never write that way).  The same switches govern the remembered ENDS of the batch vector
@@ -33,7 +33,7 @@ def plan_cache_clear():
 
 
 def plan_cache_verify(flag):
-    """Seal plans that enter the cache and verify the seal on every hit (default on)."""
+    """Verify a cached plan's seal (the checksum of the points it was built from) on every hit (default on)."""
     _ops._plan_cache(5 if flag else 6)
 
 
