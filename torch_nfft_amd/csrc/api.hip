@@ -232,6 +232,16 @@ bool work_list_forced()
     return on;
 }
 
+double items_per_cu()
+{
+    static const double v = [] {
+        const char *env = std::getenv("NFFT_HIP_ITEMS_PER_CU");
+        const double t = env ? std::atof(env) : 0.0;
+        return t >= 1.0 && t <= 64.0 ? t : 5.4;
+    }();
+    return v;
+}
+
 int stream_min_item_points()
 {
     static const int v = [] {

@@ -784,6 +784,9 @@ points_seal_kernel(const float *__restrict__ pos, const int64_t *__restrict__ ba
                 __threadfence();
                 if (__hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != *expect)
                     report_fault(status, kFaultStalePlan);
+                // leave the slot as it was found -- zero -- for the next verification that uses it: no memsets per call
+                __hip_atomic_store(acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -802,10 +805,10 @@ static int seal_launch(const float *pos, const int64_t *batch, int64_t n, int di
 
 int launch_points_verify(const float *pos, const int64_t *batch, int64_t n, int dim, void *seal, int slot, hipStream_t stream)
 {
+    // (accumulator and arrival counter of the slot are zero: the plan's count pass left them so, and every verification
+    // zeroes them again when it is through)
     unsigned long long *words = (unsigned long long *)seal;
     unsigned *arrivals = (unsigned *)(words + 9) + (slot & 7);
-    NFFT_HIP_CHECK(hipMemsetAsync(words + 1 + (slot & 7), 0, 8, stream));
-    NFFT_HIP_CHECK(hipMemsetAsync(arrivals, 0, 4, stream));
     return seal_launch(pos, batch, n, dim, words + 1 + (slot & 7), words, arrivals, stream);
 }
 

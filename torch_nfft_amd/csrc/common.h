@@ -392,10 +392,11 @@ __device__ __forceinline__ int4 listed_item(const int4 *__restrict__ sorted, con
 // launches are always enqueued; the one that is not the plan's returns at once.
 constexpr int kSegMax = 32;      // most ranges per pencil
 constexpr int kSegPieces = 16;   // most pieces a range is cut into
+double items_per_cu();  // api.hip: work items per CU the ranges of a pencil are sized for (5.4; NFFT_HIP_ITEMS_PER_CU: tuning)
 inline int64_t seg_target_points(int64_t n, int64_t nsets, int ncu)
 {
     const double per_set = (double)n / (double)(nsets > 0 ? nsets : 1);
-    const int64_t t = (int64_t)(per_set / (5.4 * (ncu > 0 ? ncu : 256)) + 0.5);
+    const int64_t t = (int64_t)(per_set / (items_per_cu() * (ncu > 0 ? ncu : 256)) + 0.5);
     return t < 2048 ? 2048 : t;
 }
 inline int seg_base_runs(int64_t n, int64_t nsets, int64_t pencils, int M, int ncu)
