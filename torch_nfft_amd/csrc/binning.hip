@@ -96,7 +96,9 @@ __device__ __forceinline__ int point_tiles(const Geom &g, const float *__restric
 // changes cancel with probability 2^-32).  The count passes of the sort form it on the side -- ~14 integer operations per
 // point; a first version with one avalanche per WORD made the instruction-bound count pass 18 % slower -- and the
 // verification of a cached plan recomputes it in one streaming pass (~25 us for 10^7 3-D points).
-constexpr int kSealThreads = 256;
+constexpr int kSealThreads = 1024;  // few, big workgroups: every one ends with two atomics on the SAME words, which serialise at
+                                    // their L2 channel (2 441 workgroups of 256 threads: 120 us for 10^7 points; 512 of 1 024: see
+                                    // profiles/r04_experiments.md -- the same effect as in plane_absmax_kernel)
 __device__ __forceinline__ unsigned long long seal_point(int dim, int64_t i, float c0, float c1, float c2, bool has_batch, int64_t b)
 {
     unsigned h = __float_as_uint(c0) * 0x9E3779B1u + (unsigned)i * 0x85EBCA77u + (unsigned)((unsigned long long)i >> 32) * 0x27D4EB2Fu;
@@ -768,7 +770,39 @@ points_seal_kernel(const float *__restrict__ pos, const int64_t *__restrict__ ba
                    unsigned *__restrict__ arrivals, int *__restrict__ status)
 {
     unsigned long long sum = 0;
-    for (int64_t i = (int64_t)blockIdx.x * kSealThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kSealThreads) {
+    const int64_t stride = (int64_t)gridDim.x * kSealThreads;
+    int64_t i = (int64_t)blockIdx.x * kSealThreads + threadIdx.x;
+    if (dim == 3 && ((uintptr_t)pos & 15) == 0 && (!batch || ((uintptr_t)batch & 15) == 0)) {
+        // 3-D (every large problem): four points = three aligned 16-byte loads (and two for their batch indices)
+        const int64_t quads = n / 4;
+        const uint4 *p4 = (const uint4 *)pos;
+        const uint4 *b4 = (const uint4 *)batch;
+        for (int64_t q = i; q < quads; q += stride) {
+            const uint4 v0 = p4[3 * q], v1 = p4[3 * q + 1], v2 = p4[3 * q + 2];
+            uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0;
+            if (batch) { w0 = b4[2 * q]; w1 = b4[2 * q + 1]; }
+            auto f = [](unsigned u) { return __uint_as_float(u); };
+            auto b64 = [](unsigned lo, unsigned hi) { return (int64_t)((unsigned long long)lo | ((unsigned long long)hi << 32)); };
+            sum += seal_point(3, 4 * q + 0, f(v0.x), f(v0.y), f(v0.z), batch != nullptr, b64(w0.x, w0.y));
+            sum += seal_point(3, 4 * q + 1, f(v0.w), f(v1.x), f(v1.y), batch != nullptr, b64(w0.z, w0.w));
+            sum += seal_point(3, 4 * q + 2, f(v1.z), f(v1.w), f(v2.x), batch != nullptr, b64(w1.x, w1.y));
+            sum += seal_point(3, 4 * q + 3, f(v2.y), f(v2.z), f(v2.w), batch != nullptr, b64(w1.z, w1.w));
+        }
+        i += 4 * quads;  // (the last n % 4 points: the loops below, which then run for the first threads only)
+        if (i >= n) i = n;
+    }
+    for (; i + 3 * stride < n; i += 4 * stride) {  // four points in flight per thread
+        float c[4][3];
+        int64_t bb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            load_point(pos, dim, i + q * stride, true, c[q][0], c[q][1], c[q][2]);
+            bb[q] = batch ? batch[i + q * stride] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sum += seal_point(dim, i + q * stride, c[q][0], c[q][1], c[q][2], batch != nullptr, bb[q]);
+    }
+    for (; i < n; i += stride) {
         float c0, c1, c2;
         load_point(pos, dim, i, true, c0, c1, c2);
         sum += seal_point(dim, i, c0, c1, c2, batch != nullptr, batch ? batch[i] : 0);
@@ -795,8 +829,8 @@ points_seal_kernel(const float *__restrict__ pos, const int64_t *__restrict__ ba
 static int seal_launch(const float *pos, const int64_t *batch, int64_t n, int dim, unsigned long long *acc,
                        const unsigned long long *expect, unsigned *arrivals, hipStream_t stream)
 {
-    int64_t blocks = (n + kSealThreads * 16 - 1) / (kSealThreads * 16);  // ~16 points per thread
-    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    int64_t blocks = (n + kSealThreads * 16 - 1) / (kSealThreads * 16);  // >= 16 points per thread
+    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
     hipLaunchKernelGGL(points_seal_kernel, dim3((unsigned)blocks), dim3(kSealThreads), 0, stream, pos, batch, n, dim, acc, expect,
                        arrivals, device_status_block());
     NFFT_HIP_CHECK(hipGetLastError());
