@@ -416,7 +416,11 @@ def main():
         # of any other leg, and a collective that never returns (the one failure a try/except cannot see) leaves the
         # headline line intact -- the process then leaves through os._exit once the line is out.
         import threading
-        worker = threading.Thread(target=lambda: guarded("C4-sharded", leg_c4_sharded), daemon=True)
+
+        def sharded_leg_thread():
+            torch.cuda.set_device(local_rank)  # (the current device is per host thread: a new thread starts on device 0)
+            guarded("C4-sharded", leg_c4_sharded)
+        worker = threading.Thread(target=sharded_leg_thread, daemon=True)
         worker.start()
         worker.join(float(os.environ.get("NFFT_BENCH_LEG_TIMEOUT", "240")))
         if worker.is_alive():

@@ -1,5 +1,6 @@
 """Developer tool: where the waves of spread_ring_kernel spend their time, per role, from a trace build
-(scripts/exp_build.sh spread_ring.hip ...:"-DNFFT_HIP_TRACE=1"; NFFT_HIP_LIB=<that library>)."""
+(the archived experiment scripts/experiments/r04_spread_ring.hip copied back to torch_nfft_amd/csrc/spread_ring.hip, hooked into
+launch_spread_mfma and built with scripts/exp_build.sh ...:"-DNFFT_HIP_TRACE=1"; NFFT_HIP_LIB=<that library>; results: profiles/r04_ring_trace.txt)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
