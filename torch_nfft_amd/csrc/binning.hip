@@ -703,6 +703,58 @@ static int launch_segment_split(const Geom &g, const PlanLayout &L, int64_t n, i
     return 0;
 }
 
+// Exclusive prefix sum of up to kSmallScanItems ints in ONE workgroup (small problems: hipCUB's device scan is two launches,
+// ~5 us of host time each, for a few thousand counters).  out[i] = in[0] + ... + in[i - 1].
+constexpr int kSmallScanItems = 1 << 16;
+__global__ void __launch_bounds__(1024) small_scan_kernel(const int *__restrict__ in, int *__restrict__ out, int items)
+{
+    __shared__ int wave_sums[16];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < items; base += 4096) {
+        // four consecutive items per thread
+        const int i0 = base + 4 * (int)threadIdx.x;
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = i0 + k < items ? in[i0 + k] : 0;
+        const int mine = v[0] + v[1] + v[2] + v[3];
+        int incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wave_sums[wave] = incl;
+        __syncthreads();
+        int before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wave_sums[w];
+        int run = before + incl - mine;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k < items) out[i0 + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = run;  // (the last thread's running sum: everything up to base + 4096)
+        __syncthreads();
+    }
+}
+
+static int exclusive_scan(const int *in, int *out, int64_t items, void *scratch, int64_t scratch_bytes, hipStream_t stream)
+{
+    if (items <= kSmallScanItems) {
+        hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(1024), 0, stream, in, out, (int)items);
+        NFFT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    size_t scan_bytes = 0;
+    NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, in, out, (int)items, stream));
+    if ((int64_t)scan_bytes > scratch_bytes) { set_error("scan scratch too small"); return 2; }
+    NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scratch, scan_bytes, in, out, (int)items, stream));
+    return 0;
+}
+
 int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, const int64_t *batch, int64_t n, int64_t B,
                        void *plan, hipStream_t stream)
 {
@@ -725,10 +777,7 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
         hipLaunchKernelGGL(common ? sort1_count_kernel<true> : sort1_count_kernel<false>, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
                            npencils, nblocks, (int)L.block_points, hist, key1, seal ? (unsigned long long *)(base + L.off_sealpart) : nullptr,
                            device_status_block());
-        size_t scan_bytes = 0;
-        NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, hist, hscan, (int)items, stream));
-        if ((int64_t)scan_bytes > L.scan_bytes) { set_error("scan scratch too small"); return 2; }
-        NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(base + L.off_scan, scan_bytes, hist, hscan, (int)items, stream));
+        if (int rc = exclusive_scan(hist, hscan, items, base + L.off_scan, L.scan_bytes, stream)) return rc;
         hipLaunchKernelGGL(common ? sort1_scatter_kernel<true> : sort1_scatter_kernel<false>, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
                            npencils, nblocks, (int)L.block_points, hscan, key1, tmp, (const unsigned long long *)(base + L.off_sealpart), seal);
         int *hist2 = (int *)(base + L.off_hist2);
@@ -749,11 +798,7 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
         hipLaunchKernelGGL(bin_count_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, g, pos, batch, n, B, cursor,
                            (unsigned long long *)(base + L.off_seal), device_status_block());
     }
-    size_t scan_bytes = 0;
-    NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, cursor, offsets, (int)(L.ntiles + 1), stream));
-    if ((int64_t)scan_bytes > L.scan_bytes) { set_error("scan scratch too small"); return 2; }
-    NFFT_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(base + L.off_scan, scan_bytes, cursor, offsets,
-                                                    (int)(L.ntiles + 1), stream));
+    if (int rc = exclusive_scan(cursor, offsets, L.ntiles + 1, base + L.off_scan, L.scan_bytes, stream)) return rc;
     NFFT_HIP_CHECK(hipMemsetAsync(cursor, 0, (L.ntiles + 1) * 4, stream));
     if (n > 0) {
         hipLaunchKernelGGL(bin_fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, g, pos, batch, n, B, offsets,
