@@ -38,7 +38,10 @@ ARITHMETIC = ("fp32 in / fp32 out; window sums on v_mfma_f32_32x32x16_f16 with t
 KERNEL_SOURCES = ("spread_mfma.hip", "common.h", "mfma_split.h", "window.h")
 TRAFFIC_RECORD = "r04_spread_traffic.json"
 # gather kernel at C3: FETCH_SIZE x 2 + WRITE_SIZE from the committed PMC passes (builder-measured)
-INTERP_TRAFFIC = {"bytes": None, "source": "profiles/r04_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, builder-measured)"}
+# (8.532e5 KiB x 2 fetched + 3.205e5 KiB written per launch of interp_stream_kernel<10, false, 3>)
+INTERP_TRAFFIC = {"bytes": int((8.532e5 * 2 + 3.205e5) * 1024),
+                  "source": "profiles/r04_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE passes of this command at "
+                            "C3, builder-measured in round 4, replayed here; not measured by this run)"}
 TRAFFIC_SOURCE = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE (x2, the gfx950 correction) and WRITE_SIZE passes of this command, "
                   "taken by the builder (scripts/profile_round.sh) and replayed here while the kernel's name, the workload and "
                   "the hash of the kernel's source files still match; null otherwise -- not measured by this run" % TRAFFIC_RECORD)
