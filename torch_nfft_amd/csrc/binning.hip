@@ -822,17 +822,30 @@ points_seal_kernel(const float *__restrict__ pos, const int64_t *__restrict__ ba
         const int64_t quads = n / 4;
         const uint4 *p4 = (const uint4 *)pos;
         const uint4 *b4 = (const uint4 *)batch;
-        for (int64_t q = i; q < quads; q += stride) {
-            const uint4 v0 = p4[3 * q], v1 = p4[3 * q + 1], v2 = p4[3 * q + 2];
-            uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0;
-            if (batch) { w0 = b4[2 * q]; w1 = b4[2 * q + 1]; }
-            auto f = [](unsigned u) { return __uint_as_float(u); };
-            auto b64 = [](unsigned lo, unsigned hi) { return (int64_t)((unsigned long long)lo | ((unsigned long long)hi << 32)); };
+        auto f = [](unsigned u) { return __uint_as_float(u); };
+        auto b64 = [](unsigned lo, unsigned hi) { return (int64_t)((unsigned long long)lo | ((unsigned long long)hi << 32)); };
+        auto four = [&](const int64_t q, const uint4 v0, const uint4 v1, const uint4 v2, const uint4 w0, const uint4 w1) {
             sum += seal_point(3, 4 * q + 0, f(v0.x), f(v0.y), f(v0.z), batch != nullptr, b64(w0.x, w0.y));
             sum += seal_point(3, 4 * q + 1, f(v0.w), f(v1.x), f(v1.y), batch != nullptr, b64(w0.z, w0.w));
             sum += seal_point(3, 4 * q + 2, f(v1.z), f(v1.w), f(v2.x), batch != nullptr, b64(w1.x, w1.y));
             sum += seal_point(3, 4 * q + 3, f(v2.y), f(v2.z), f(v2.w), batch != nullptr, b64(w1.z, w1.w));
+        };
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        int64_t q = i;
+        for (; q + 2 * stride < quads; q += 3 * stride) {  // three groups of four points (nine 16-byte loads) in flight per thread
+            uint4 v[3][3], w[3][2];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int64_t qq = q + u * stride;
+                v[u][0] = p4[3 * qq]; v[u][1] = p4[3 * qq + 1]; v[u][2] = p4[3 * qq + 2];
+                w[u][0] = batch ? b4[2 * qq] : z4;
+                w[u][1] = batch ? b4[2 * qq + 1] : z4;
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) four(q + u * stride, v[u][0], v[u][1], v[u][2], w[u][0], w[u][1]);
         }
+        for (; q < quads; q += stride)
+            four(q, p4[3 * q], p4[3 * q + 1], p4[3 * q + 2], batch ? b4[2 * q] : z4, batch ? b4[2 * q + 1] : z4);
         i += 4 * quads;  // (the last n % 4 points: the loops below, which then run for the first threads only)
         if (i >= n) i = n;
     }
