@@ -10,7 +10,7 @@ for f in api.hip binning.hip spread.hip spread_reg.hip spread_mfma.hip interp.hi
 done
 for spec in "$@"; do
   name=${spec%%:*}; rest=${spec#*:}; src=${rest%%:*}; flags=${rest#*:}
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -ffp-contract=fast -fno-slp-vectorize $flags -Itorch_nfft_amd/csrc -I/opt/rocm/include -x hip -c $src -o /tmp/exp_$name.o && \
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -ffp-contract=on -fno-slp-vectorize $flags -Itorch_nfft_amd/csrc -I/opt/rocm/include -x hip -c $src -o /tmp/exp_$name.o && \
     /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -Wl,-soname,libnfft_hip.so -o scripts/ubench/libnfft_$name.so $OBJS /tmp/exp_$name.o -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib ) &
 done
 wait
