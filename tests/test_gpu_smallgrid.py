@@ -76,7 +76,7 @@ def test_fused_vs_oracle(tn, d, N, m, complex_x):
     """three point sets (the middle one EMPTY), two columns, both directions, complex and real_output results"""
     from torch_nfft_amd import _lib
     rng = np.random.default_rng(9000 + 100 * d + N + m)
-    # (the fused path takes at most 6e4 window taps per point set on average: fewer points for the wide windows)
+    # (the fused path takes at most 8e4 window taps per point set on average: fewer points for the wide windows)
     taps = (2 * m + 2) ** d
     big = max(2, min(402, int(0.55 * 180000 // taps)))
     sizes = [max(1, int(0.77 * big)), 0, big]
@@ -110,7 +110,7 @@ def test_fused_and_general_path_agree(tn, d, N, m, B):
     from torch_nfft_amd import _lib
     lib = _lib.load()
     rng = np.random.default_rng(31 + N + d)
-    n, C = int(0.9 * 60000 * min(B, 8) // (2 * m + 2) ** d), 3  # (6e4 window taps per set is the fused path's limit)
+    n, C = int(0.9 * 80000 * min(B, 8) // (2 * m + 2) ** d), 3  # (8e4 window taps per set is the fused path's limit)
     sizes = None if B == 1 else list(rng.multinomial(n, np.ones(B) / B))
     pos, batch, x = _problem(rng, n, sizes, (C,), True, d)
     prob = _lib.Problem(d, n, C, B, N, m)

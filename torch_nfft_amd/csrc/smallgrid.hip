@@ -22,8 +22,10 @@ constexpr int kSgThreads = 1024;          // (16 waves: the LDS atomics and read
 constexpr int kSgMaxCells = 4096;         // grid cells: 16 B of fp64 sums + 8 B of FFT buffer per cell (+ twiddles)
 // average window taps per point set: a set is ONE workgroup's loop, ~0.35 ns per tap and direction (LDS atomics of a single
 // CU) on top of ~25 us per adjoint + forward pair, against 80-145 us for the general path on these sizes -- measured
-// break-even ~10^5 taps (profiles/r03_experiments.md)
-constexpr int64_t kSgMaxSetTaps = 60000;
+// break-even ~10^5 taps (profiles/r03_experiments.md).  8e4 since round 4: the reference's own test shape (test/test_adjoint.py:
+// 2-D N = 16, m = 3, 1 000 points per set = 64 000 taps) sat just above the first limit of 6e4 and took the general path
+// (0.122 ms against 0.07 here, profiles/r04_experiments.md)
+constexpr int64_t kSgMaxSetTaps = 80000;
 
 bool small_grid_supported(const nfft_hip_problem *p)
 {
