@@ -152,14 +152,16 @@ def test_config_c3_clustered_10m(tn):
     assert abs(complex(lhs) - complex(rhs)) < 1e-4 * abs(complex(lhs)) + 1e-2
 
 
-@pytest.mark.parametrize("complex_x,real_output,chunk_planes", [(False, True, 5), (True, False, 5), (True, True, 7),
-                                                                 (False, False, 3)])
-def test_config_c4_shape_batched_columns_chunked(tn, monkeypatch, complex_x, real_output, chunk_planes):
+@pytest.mark.parametrize("complex_x,real_output,chunk_planes,C", [(False, True, 5, 4), (True, False, 5, 4), (True, True, 7, 4),
+                                                                   (False, False, 3, 4), (False, True, 2, 3), (False, False, 4, 5)])
+def test_config_c4_shape_batched_columns_chunked(tn, monkeypatch, complex_x, real_output, chunk_planes, C):
     """Config C4's structure (3-D N=128, m=4, several point sets x several columns) at a size that runs in seconds,
     with an odd chunk budget that forces the plane loop of the planar-copy column passes (chunks that start in the
     middle of a point set, (re, im) plane pairs for complex data): subset of frequencies vs the exact NDFT per
     (batch, column), sparse-spectrum forward vs the exact sums, adjointness."""
-    N, m, B, C, n_per = 128, 4, 3, 4, 20_000
+    # (round 4: the owner-computes spreading kernel sweeps the points once per PAIR of columns -- the chunks here start and
+    # end inside pairs, and the odd column counts leave every point set's last column to a sweep of its own)
+    N, m, B, n_per = 128, 4, 3, 20_000
     gen = torch.Generator(device="cuda").manual_seed(7)
     pos = torch.rand((B * n_per, 3), generator=gen, device="cuda") - 0.5
     batch = torch.arange(B * n_per, device="cuda") // n_per

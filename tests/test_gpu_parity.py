@@ -623,16 +623,18 @@ def test_columns_of_very_different_magnitude(tn):
 
 # ----------------------------------------------------------------------------- owner-computes spreading (sparse inputs)
 
-@pytest.mark.parametrize("m", [1, 4, 7])
-def test_owned_spreading_stage_tile_borders(tn, m):
-    """Sparse 3-D problems spread by owner-computes (32 x 64 tiles, a plan entry per touched tile, plain stores):
-    points on tile corners and edges, on the torus boundary, in neighbouring point sets, several columns -- the spread
-    grid against the oracle's gridding, written completely (the grid is pre-filled with NaN) and bitwise reproducible."""
+@pytest.mark.parametrize("m,Cr", [(1, 2), (4, 2), (7, 2), (4, 1), (4, 3), (2, 5), (7, 3)])
+def test_owned_spreading_stage_tile_borders(tn, m, Cr):
+    """Sparse 3-D problems spread by owner-computes (a plan entry per touched tile, plain stores; one column: 32 x 64
+    tiles, one sweep of the points per column; two or more: 32 x 32 tiles, one sweep per PAIR of columns -- an odd column
+    count leaves every point set's last column to a sweep of its own): points on tile corners and edges, on the torus
+    boundary, in neighbouring point sets -- the spread grid against the oracle's gridding, written completely (the grid is
+    pre-filled with NaN) and bitwise reproducible."""
     import ctypes
     from torch_nfft_amd import _lib
     lib = _lib.load()
     rng = np.random.default_rng(510 + m)
-    d, N, B, Cr = 3, 64, 3, 2
+    d, N, B = 3, 64, 3
     M = 2 * N
     cells = np.array([0, 1, 30, 31, 32, 33, 62, 63, 64, 65, 95, 96, 126, 127])
     corner = np.stack(np.meshgrid(cells, cells[::3], cells, indexing="ij"), -1).reshape(-1, 3)

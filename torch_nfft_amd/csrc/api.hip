@@ -252,6 +252,16 @@ int stream_min_item_points()
     return v;
 }
 
+// NFFT_HIP_OWNED_PAIR=0: owned plans keep the 32 x 64 tiles and the one-column sweeps for every column count
+bool owned_pair_enabled()
+{
+    static const bool on = [] {
+        const char *env = std::getenv("NFFT_HIP_OWNED_PAIR");
+        return !(env && env[0] == '0');
+    }();
+    return on;
+}
+
 int owned_override()
 {
     static const int v = [] {
@@ -299,7 +309,8 @@ PlanSet plan_set(const nfft_hip_problem *p)
     ps.off_own = 0;
     ps.total = ps.L.total;
     if (ps.owned) {
-        ps.go = make_geom(p->dim, p->N, p->m, true);
+        // two or more coefficient columns: 32 x 32 tiles, one sweep of the points per PAIR of columns (spread_mfma.hip)
+        ps.go = make_geom(p->dim, p->N, p->m, true, p->num_columns >= 2 && owned_pair_enabled());
         ps.Lo = plan_layout(ps.go, p->num_points, p->batch_size);
         ps.off_own = align_up(ps.L.total, 256);
         ps.total = ps.off_own + ps.Lo.total;

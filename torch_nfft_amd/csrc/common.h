@@ -50,9 +50,11 @@ struct TileCfg {
 // T1 + W - 1 = 32 rows and T2 + W - 1 = 64 columns, and the plan is sorted by single planes ("slabs").
 // Owned tiling (owner-computes variant of the MFMA spreading kernel, sparse inputs): the accumulator tile IS the owned
 // region, T1 = 32, T2 = 64, and a point is entered into every tile its window touches (1, 2 or 4 plan entries).
-constexpr TileCfg tile_cfg(int dim, int W, bool wide = false, bool owned = false)
+// Paired owned tiling (problems with two or more coefficient columns): T2 = 32 -- a wave's two accumulator tiles hold the
+// same 32 x 32 cells of TWO columns' grids, so that one sweep over the points (one set of operand tables) serves both.
+constexpr TileCfg tile_cfg(int dim, int W, bool wide = false, bool owned = false, bool pair = false)
 {
-    return dim == 3 ? (owned ? TileCfg{32, 64, (W <= 16 ? 17 - W : 1) + W - 1, W <= 16 ? 17 - W : 1}
+    return dim == 3 ? (owned ? TileCfg{32, pair ? 32 : 64, (W <= 16 ? 17 - W : 1) + W - 1, W <= 16 ? 17 - W : 1}
                      : wide ? TileCfg{33 - W, 65 - W, (W <= 16 ? 17 - W : 1) + W - 1, W <= 16 ? 17 - W : 1}
                      : W <= 12 ? TileCfg{16, 32, 16, 16 - (W - 1)}
                      : W <= 14 ? TileCfg{8, 32, 16, 16 - (W - 1)}
@@ -89,6 +91,7 @@ struct Geom {
     int wide;     // wide (MFMA) tiling; the plan then has one bin per plane along axis 0
     int owned;    // owned variant of the wide tiling: 32 x 64 tiles without halo, a point has an entry in every tile
                   // its window touches (spreading by owner-computes: plain stores, no zero-fill, no atomics)
+    int pair;     // owned tiling with 32 x 32 tiles: the spreading kernel sweeps the points once for two coefficient columns
     int bin0;     // planes per plan bin along axis 0: Ta[0], or 1 for the wide tiling
     int np0;      // plan bins per pencil along axis 0
     int tiles_per_batch;  // plan bins per point set: np0 * nta[1] * nta[2]
@@ -120,7 +123,7 @@ unsigned next_launch_number();             // api.hip: process-wide, never 0
 bool work_list_forced();       // api.hip: NFFT_HIP_WORK_LIST=1 runs every wide plan from its work list
 bool column_groups_enabled();  // api.hip: NFFT_HIP_COLGROUPS=0 turns the column-group order of the plan off
 
-inline Geom make_geom(int dim, int64_t N, int64_t m, bool owned = false)
+inline Geom make_geom(int dim, int64_t N, int64_t m, bool owned = false, bool pair = false)
 {
     Geom g;
     g.dim = dim;
@@ -139,7 +142,8 @@ inline Geom make_geom(int dim, int64_t N, int64_t m, bool owned = false)
     g.wide = dim == 3 && spread_mode() == kSpreadMfma && g.M >= 64 && g.M <= 1024 && g.W <= 16;
     // at least two tiles per axis, so that a window never touches the same tile from both sides of the torus
     g.owned = owned && g.wide && g.M >= 128 && g.M % 64 == 0;
-    const TileCfg tc = tile_cfg(dim, g.W, g.wide != 0, g.owned != 0);
+    g.pair = g.owned && pair;
+    const TileCfg tc = tile_cfg(dim, g.W, g.wide != 0, g.owned != 0, g.pair != 0);
     g.Ta[0] = tc.TC;
     g.Ta[1] = tc.T1;
     g.Ta[2] = tc.T2;

@@ -225,7 +225,8 @@ PlanLookup plan_lookup_key(const Points &p, const nfft_hip_problem &q)
     key.pos_ptr = p.pos.data_ptr();
     key.batch_ptr = p.batch.defined() ? p.batch.data_ptr() : nullptr;
     key.n = p.n; key.B = p.B; key.N = q.N; key.m = q.m; key.dim = p.dim; key.device = p.pos.device().index();
-    key.flags = q.flags;
+    // (the owner-computes spreading plan of a sparse problem has another tiling from two columns up: api.hip plan_set)
+    key.flags = q.flags | (q.num_columns >= 2 ? (1 << 30) : 0);
     lk.use_cache = g_cache.enabled && cacheable;  // (read under the lock by the callers below)
     if (lk.use_cache) {
         key.pos_version = (int64_t)p.pos._version();

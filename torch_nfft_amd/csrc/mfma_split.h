@@ -98,6 +98,8 @@ __device__ __forceinline__ void lds_dma_dwordx4(const float *gsrc, const void *l
 __device__ __forceinline__ void wait_lds_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // all but the newest request (2 LDS-DMA instructions: the point record and the coefficient) have landed
 __device__ __forceinline__ void wait_lds_dma_but_newest() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+// ... with two coefficient columns per sweep: 3 instructions per step
+__device__ __forceinline__ void wait_lds_dma_but_newest3() { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
 // workgroup barrier that leaves global traffic (LDS-DMA, flush atomics) in flight
 __device__ __forceinline__ void barrier_lds_only() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 

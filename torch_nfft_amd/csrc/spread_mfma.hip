@@ -102,6 +102,7 @@ struct __align__(16) MfmaOps {
 // Points of one batch (cell fractions, in-pencil cells, scaled value), double-buffered as well.
 struct __align__(16) MfmaStage {
     float f0[kSlots], f1[kSlots], f2[kSlots], x[kSlots];
+    float x1[kSlots];                     // (paired variant: the second column's scaled value)
     int c1[kSlots], c2[kSlots];
     int slab[kNKB];
 };
@@ -117,26 +118,37 @@ struct __align__(16) MfmaLds {
     MfmaStage stag[2];
     f32x4 raw[kRecRing][kSlots];          // landing zones of the LDS-DMA (batch b uses b & 7): plan records {p0, p1, p2, index}
     float rawx[kXRing][kSlots];           // ... and of the coefficients (batch b uses b & 3)
+    float rawx1[kXRing][kSlots];          // (paired variant: the second column's)
     int raw_idx[kRecRing][kSlots];        // plan entry of the slot (only used with the plan-ordered coefficient copy)
     signed char raw_have[kRecRing][kSlots];
     int raw_slab[kRecRing][kNKB];
     int task_counter[2];
     int ticket;                           // work-list entry of the workgroup (persistent launch: next_work_item)
     float inv_xscale;                     // (read by the staging threads once per step: a register would be spilled to scratch)
+    float inv_xscale1;                    // (paired variant: the second column's plane)
     int2 sched[kMaxSweep + 8];            // per slab: {K-blocks before it, point offset}; padded with the totals
     int sched_end[kMaxSweep + 8];         // per slab: end of its point range
 };
 static_assert(sizeof(MfmaLds<16>) <= 160 * 1024, "LDS budget");
 
-template <int W, bool OVERFLOW, bool OWNED>
+// Paired variant (template flag PAIR, owned plans of problems with two or more columns: 32 x 32 tiles): accumulator 0 holds
+// the tile of real column 2q of the point set, accumulator 1 the SAME cells of column 2q + 1 -- the points are staged once,
+// the B fragments (psi2) and the psi1 table are built once, only the axis-0 table (x' psi0) and the A fragment exist per
+// column.  At C4's density (10^5 points per 256^3 grid) the kernel's time is its K-block count, not its stores (measured:
+// profiles/r04_experiments.md), and a 32 x 32 tile's slab holds ~10 points -- one K-block -- where a 32 x 64 tile's held ~18,
+// i.e. two half-empty ones per column.  The y grid of the launch enumerates pair slots: slot s = (point set, pair) covers
+// planes set * Cr + 2 pair (+ 1); a chunk of planes that starts or ends inside a pair runs that slot with one column.
+template <int W, bool OVERFLOW, bool OWNED, bool PAIR>
 __global__ void __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const float *__restrict__ spos,
                    const float *__restrict__ xr, const float *__restrict__ xs, const int64_t xs_stride,
                    const unsigned *__restrict__ xmax, const int Cr,
-                   const int plane0, float *__restrict__ grid, const int seg_slabs, const int nsegm,
+                   const int plane0, const int nplanes, float *__restrict__ grid, const int seg_slabs, const int nsegm,
                    const int4 *__restrict__ work, const int4 *__restrict__ sorted, const WorkTickets tickets, int *__restrict__ status)
 {
+    static_assert(!PAIR || OWNED, "the paired variant is an owner-computes kernel");
     constexpr int m = W / 2 - 1;
+    constexpr int TW = PAIR ? 32 : 64;  // columns of the accumulator tile
     extern __shared__ __align__(16) unsigned char smem_raw[];
     MfmaLds<W> &L = *reinterpret_cast<MfmaLds<W> *>(smem_raw);
 
@@ -147,7 +159,21 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     NFFT_TRACE(0, __builtin_amdgcn_s_memrealtime());
     NFFT_TRACE(4, (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32));
 
-    const int plane_local = blockIdx.y;
+    // plane(s) of this workgroup: one, or the pair slot's two (the second one may be missing: odd column count, or a chunk
+    // of planes that ends inside the pair; a chunk that STARTS inside a pair runs the pair's second column alone)
+    int plane_local = blockIdx.y, plane_local1 = -1;
+    if constexpr (PAIR) {
+        const int P = (Cr + 1) >> 1;  // pair slots per point set
+        const int b0 = plane0 / Cr, c0 = plane0 - b0 * Cr;
+        const int slot = b0 * P + (c0 >> 1) + (int)blockIdx.y;
+        const int sb_ = slot / P, q = slot - sb_ * P;
+        const int pa = sb_ * Cr + 2 * q - plane0;  // local plane of the pair's first column
+        const bool va = pa >= 0 && pa < nplanes, vb = 2 * q + 1 < Cr && pa + 1 >= 0 && pa + 1 < nplanes;
+        if (!va && !vb) return;  // (cannot happen for the slots the launch enumerates)
+        plane_local = va ? pa : pa + 1;
+        plane_local1 = va && vb ? pa + 1 : -1;
+    }
+    const bool two = PAIR && plane_local1 >= 0;  // workgroup-uniform
     const int plane = plane0 + plane_local;
     const int b = plane / Cr;
     const int cr = plane - b * Cr;
@@ -162,8 +188,8 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     const int2 set_hdr = OVERFLOW ? ((const int2 *)(work + 1))[b] : make_int2(1, 0);
     const int n_items = set_hdr.x;
     const int4 *const entries = sorted + set_hdr.y;
-    for (int item = OVERFLOW ? next_work_item(tickets, &L.ticket, -1, plane_local) : 0; item < n_items;
-         item = OVERFLOW ? next_work_item(tickets, &L.ticket, item, plane_local) : 1) {
+    for (int item = OVERFLOW ? next_work_item(tickets, &L.ticket, -1, (int)blockIdx.y) : 0; item < n_items;
+         item = OVERFLOW ? next_work_item(tickets, &L.ticket, item, (int)blockIdx.y) : 1) {
     if (OVERFLOW && item != (int)blockIdx.x) __syncthreads();  // the previous item is done with the LDS
     int pencil, sb, se;
     if constexpr (OVERFLOW) {
@@ -195,28 +221,41 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     // carries (one or two real columns: no permutation pass anywhere), or `xs`, a copy in plan order, one column after
     // the other (gather_rows: more columns).  Both arrive through the staging pipeline below.
     const float *const xcol = xs + (int64_t)cr * xs_stride;
+    [[maybe_unused]] const float *const xcol1 = xcol + (two ? xs_stride : 0);  // (paired variant: column cr + 1)
     // x is scaled into [-1, 1] by a power of two so that every operand fits f16; undone at the flush.  The scale is the
     // plane's own -- the largest |x| of its point set in its column, found by plane_absmax_kernel before the launch --
     // so columns and point sets of very different magnitude each keep their full ~22 bits (a single scale for the whole
     // call would flush a column 1e-10 below the largest one to zero; the reference spreads every column independently
     // in fp32).  (Until round 3 every work item scanned its own points for it: a latency-bound prologue, 7 % of the
     // kernel's time at config C3, profiles/r03_spread_trace.txt.)
-    float xscale = 1.0f;
-    {
-        const float mx = __uint_as_float(xmax[plane]);
+    auto plane_scale = [&](const int pl) {
+        float sc1 = 1.0f;
+        const float mx = __uint_as_float(xmax[pl]);
         if (mx > 1.0e-30f && mx < 3.0e38f) {  // (tinier inputs: 1 / scale would overflow; their taps flush to zero anyway)
             int e;
             frexpf(mx, &e);
-            xscale = ldexpf(1.0f, e > 127 ? 127 : e);  // (|x| in [2^127, 3e38): 2^128 is not a float; 1 / it would be 0)
+            sc1 = ldexpf(1.0f, e > 127 ? 127 : e);  // (|x| in [2^127, 3e38): 2^128 is not a float; 1 / it would be 0)
         }
-    }
-    // (wave-uniform: keep the scales in scalar registers -- the kernel sits at its 128-VGPR limit)
-    xscale = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(xscale)));
+        // (wave-uniform: keep the scales in scalar registers -- the kernel sits at its 128-VGPR limit)
+        return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sc1)));
+    };
+    const float xscale = plane_scale(plane);
     NFFT_TRACE(1, __builtin_amdgcn_s_memrealtime());
     if (tid == 0) L.inv_xscale = 1.0f / xscale;  // (visible behind the barriers of the schedule set-up below)
     const float unscale =
         __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(xscale * norm * (1.0f / (kOpScale * kOpScale * kPsiScale)))));
     float *const gplane = grid + (int64_t)plane_local * g.cells;
+    [[maybe_unused]] float unscale1 = 0.0f;
+    [[maybe_unused]] float *gplane1 = nullptr;
+    if constexpr (PAIR) {
+        if (two) {
+            const float xscale1 = plane_scale(plane + 1);
+            if (tid == 0) L.inv_xscale1 = 1.0f / xscale1;
+            unscale1 = __int_as_float(
+                __builtin_amdgcn_readfirstlane(__float_as_int(xscale1 * norm * (1.0f / (kOpScale * kOpScale * kPsiScale)))));
+            gplane1 = grid + (int64_t)plane_local1 * g.cells;
+        }
+    }
 
     f32x16 acc0 = 0.0f, acc1 = 0.0f;
     bool dirty = false;
@@ -225,6 +264,9 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     // full time instead of idling through the accumulation)
     constexpr int NOWN = W <= 12 ? 12 : 16;
     const bool owner = wave < NOWN;
+#ifdef NFFT_BUILDER_PRIO
+    if (!owner) __builtin_amdgcn_s_setprio(NFFT_BUILDER_PRIO);
+#endif
     const int z_lo = OWNED ? sb : sb - m;  // first plane any owner holds
     int myz = z_lo + (((wave - z_lo) % NOWN) + NOWN) % NOWN;
     // staging threads: the first two non-owner waves if there are any, else waves 0 and 1
@@ -233,7 +275,32 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     const bool stager = (unsigned)st < (unsigned)kSlots;
 
     auto flush = [&]() __attribute__((always_inline)) {
-        if constexpr (OWNED) {
+        if constexpr (PAIR) {
+            // accumulator 0 = the 32 x 32 tile of the first column's grid, accumulator 1 = the same cells of the second
+            // column's: four 16-byte stores per lane and grid (transposed tile as below: lane = grid row)
+            if (owner && myz >= sb && myz < se) {
+                const int64_t off = ((int64_t)myz * g.M + tb1 + r32) * g.M + tb2 + 4 * h;
+                const float zs0 = ((myz + m) & 1) ? -unscale : unscale;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
+                    v.x = acc0[4 * q + 0] * zs0; v.y = acc0[4 * q + 1] * zs0; v.z = acc0[4 * q + 2] * zs0; v.w = acc0[4 * q + 3] * zs0;
+                    *(f32x4 *)(gplane + off + 8 * q) = v;
+                }
+                if (two) {
+                    const float zs1 = ((myz + m) & 1) ? -unscale1 : unscale1;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+                        v.x = acc1[4 * q + 0] * zs1; v.y = acc1[4 * q + 1] * zs1; v.z = acc1[4 * q + 2] * zs1; v.w = acc1[4 * q + 3] * zs1;
+                        *(f32x4 *)(gplane1 + off + 8 * q) = v;
+                    }
+                }
+            }
+            acc0 = 0.0f;
+            acc1 = 0.0f;
+            dirty = false;
+        } else if constexpr (OWNED) {
             // every owned plane is written exactly once, whether or not points reached it
             if (owner && myz >= sb && myz < se) {  // (the builder waves own nothing)
                 // the owned variant accumulates the TRANSPOSED tile (operands swapped in the MFMA): lane = grid row,
@@ -338,9 +405,14 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     const int nbatch = (total + kNKB - 1) / kNKB;
     if (OWNED && total == 0) {
         // no points anywhere near these planes: they are still this item's to write
-        for (int e = tid; e < nplane * 512; e += kMfmaThreads) {
-            const int pz = e >> 9, row = (e >> 4) & 31, c4 = e & 15;
-            *(f32x4 *)(gplane + ((int64_t)(sb + pz) * g.M + tb1 + row) * g.M + tb2 + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int QW = TW / 4;  // 16-byte pieces per tile row
+        for (int e = tid; e < nplane * 32 * QW; e += kMfmaThreads) {
+            const int pz = e / (32 * QW), row = (e / QW) & 31, c4 = e & (QW - 1);
+            const int64_t off = ((int64_t)(sb + pz) * g.M + tb1 + row) * g.M + tb2 + 4 * c4;
+            *(f32x4 *)(gplane + off) = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (PAIR) {
+                if (two) *(f32x4 *)(gplane1 + off) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         continue;
     }
@@ -402,13 +474,21 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
             src = xcol + L.raw_idx[batch & (kRecRing - 1)][st];
         }
         lds_dma_dword(src, &L.rawx[batch & (kXRing - 1)][(wave - kStageWave0) * 64]);
+        if constexpr (PAIR) {
+            // the second column's coefficient (the same address again in a slot of one column: the count of DMA
+            // instructions per step stays uniform)
+            const float *src1 = xr ? src + (two ? 1 : 0) : xcol1 + L.raw_idx[batch & (kRecRing - 1)][st];
+            lds_dma_dword(src1, &L.rawx1[batch & (kXRing - 1)][(wave - kStageWave0) * 64]);
+        }
     };
     auto stage_convert = [&](MfmaStage &S, const int batch, const bool newest_in_flight) {
         const int buf = batch & (kRecRing - 1);
         // the stager waves of the 12-owner layout issue no other vector-memory traffic: a counted wait leaves the two
         // requests of the previous step in flight (plane-owner waves also have flush atomics outstanding: wait for all)
-        if (newest_in_flight && NOWN != 16) wait_lds_dma_but_newest(); else wait_lds_dma();
+        if (newest_in_flight && NOWN != 16) { if constexpr (PAIR) wait_lds_dma_but_newest3(); else wait_lds_dma_but_newest(); }
+        else wait_lds_dma();
         float f0 = 0.f, f1 = 0.f, f2 = 0.f, xv = 0.f;
+        [[maybe_unused]] float xv1 = 0.f;
         int c1 = -1000, c2 = -1000;  // padding slots: outside every window
         if (L.raw_have[buf][st]) {
             int c0;
@@ -422,7 +502,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                 c2 -= tb2;
                 // (periodic image whose window reaches the tile: offsets in [-m - 1, T + m); M >= 128 keeps it unique)
                 c1 = c1 >= 32 + m ? c1 - g.M : (c1 < -(m + 1) ? c1 + g.M : c1);
-                c2 = c2 >= 64 + m ? c2 - g.M : (c2 < -(m + 1) ? c2 + g.M : c2);
+                c2 = c2 >= TW + m ? c2 - g.M : (c2 < -(m + 1) ? c2 + g.M : c2);
             } else {
                 c1 -= tb1 - m;  // row of the point's cell inside the padded pencil (tap l1 sits at row c1 - m + l1)
                 c2 -= tb2 - m;
@@ -435,7 +515,17 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                 report_fault(status, kFaultBatchOrder);
                 xv = fminf(fmaxf(xv, -1.0f), 1.0f);
             }
+            if constexpr (PAIR) {
+                if (two) {
+                    xv1 = L.rawx1[batch & (kXRing - 1)][st] * L.inv_xscale1;
+                    if (fabsf(xv1) > 1.0f && fabsf(xv1) < __builtin_huge_valf()) {
+                        report_fault(status, kFaultBatchOrder);
+                        xv1 = fminf(fmaxf(xv1, -1.0f), 1.0f);
+                    }
+                }
+            }
         }
+        if constexpr (PAIR) S.x1[st] = xv1;
         S.f0[st] = f0; S.f1[st] = f1; S.f2[st] = f2; S.x[st] = xv;
         S.c1[st] = c1; S.c2[st] = c2;
         if ((st & (kKB - 1)) == 0) S.slab[st / kKB] = L.raw_slab[buf][st / kKB];  // written by this same thread
@@ -447,6 +537,9 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     [[maybe_unused]] int tasks_taken = 0;  // (trace builds only)
     auto build_tasks = [&](const MfmaStage &S, MfmaOps<W> &O, const int nkb, int *counter) {
         tasks_taken = 0;
+#ifdef NFFT_BUILD_PRIO
+        if (owner) __builtin_amdgcn_s_setprio(NFFT_BUILD_PRIO);
+#endif
         while (true) {
             // all 64 lanes add 1 (the compiler folds this into one ds_add of 64 per wave): the counter runs in units of
             // 64, lane 0 sees the wave's base value
@@ -462,8 +555,10 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                 const f16x8 zero = (_Float16)0.0f;
                 O.bfrag[j][0][0][lane] = zero;
                 O.bfrag[j][0][1][lane] = zero;
-                O.bfrag[j][1][0][lane] = zero;
-                O.bfrag[j][1][1][lane] = zero;
+                if constexpr (!PAIR) {  // (paired variant: one column tile; the second one's space holds the second axis-0 table)
+                    O.bfrag[j][1][0][lane] = zero;
+                    O.bfrag[j][1][1][lane] = zero;
+                }
                 f32x4 *pz = (f32x4 *)&O.p1[j][0][0][0][0];  // 2 x 2 x 32 x 8 halves = 128 x 16 bytes
                 const f32x4 zero4 = 0.0f;
                 pz[lane] = zero4;
@@ -476,6 +571,9 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
             const int slot = j * kKB + k;
             const int c2v = S.c2[slot], c1v = S.c1[slot];
             const float f2v = S.f2[slot], f1v = S.f1[slot], f0v = S.f0[slot], xv = S.x[slot];
+            [[maybe_unused]] const float xv1 = PAIR ? S.x1[slot] : 0.0f;
+            // (paired variant) axis-0 table of the second column, [tap][hi/lo][point], in the unused second column tile
+            [[maybe_unused]] _Float16 *const a1 = (_Float16 *)&O.bfrag[j][1][0][0];
             const int sl = S.slab[j];
             int touched = 0;
             _Float16 *const base_h = (_Float16 *)&O.bfrag[j][0][0][32 * (k >> 3)] + (k & 7);
@@ -489,7 +587,7 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                     const float v = __builtin_amdgcn_exp2f(sc * d * d) * kOpScale;
                     unsigned hi, lo;
                     split_pair(v, 0.0f, hi, lo);
-                    if (l < W && (unsigned)col < 64u) {  // (padding slots fail the second test)
+                    if (l < W && (unsigned)col < (unsigned)TW) {  // (padding slots fail the second test)
                         // element [col >> 5][hi/lo][32 (k >> 3) + (col & 31)][k & 7] of bfrag[j]
                         _Float16 *ph = base_h + (col >> 5) * (2 * 64 * 8) + (col & 31) * 8;
                         ph[0] = __builtin_bit_cast(_Float16, (unsigned short)hi);
@@ -518,6 +616,15 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                             O.p1[j][1][k >> 3][row][k & 7] = __builtin_bit_cast(_Float16, (unsigned short)lo);
                         }
                     }
+                    if constexpr (PAIR) {
+                        const float vb = xv1 * __builtin_amdgcn_exp2f(sc * d0 * d0) * sgn;
+                        unsigned hi1, lo1;
+                        split_pair(vb, 0.0f, hi1, lo1);
+                        if (l < W) {
+                            a1[(l * 2 + 0) * kKB + k] = __builtin_bit_cast(_Float16, (unsigned short)hi1);
+                            a1[(l * 2 + 1) * kKB + k] = __builtin_bit_cast(_Float16, (unsigned short)lo1);
+                        }
+                    }
                 }
             }
             // the plan orders a slab's points by column group (common.h): most K-blocks touch one tile only
@@ -528,6 +635,9 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                 O.slab[j] = sl;
             }
         }
+#ifdef NFFT_BUILD_PRIO
+        if (owner) __builtin_amdgcn_s_setprio(0);
+#endif
     };
 
     // ---- every wave adds the K-blocks that reach its plane -------------------------------------------------
@@ -553,6 +663,29 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                 u32x4 uh, ul;
                 split_product_f16x4(ph, pl, xh, xl, uh, ul);
                 const f16x8 ah = __builtin_bit_cast(f16x8, uh), al = __builtin_bit_cast(f16x8, ul);
+                if constexpr (PAIR) {
+                    // one column tile, two columns: the B fragments serve both chains
+                    const f16x8 b0h = O.bfrag[j][0][0][lane], b0l = O.bfrag[j][0][1][lane];
+                    if (two) {
+                        const _Float16 *const a1 = (const _Float16 *)&O.bfrag[j][1][0][0];
+                        const u32x4 yh = *(const u32x4 *)&a1[(l0 * 2 + 0) * kKB + 8 * h], yl = *(const u32x4 *)&a1[(l0 * 2 + 1) * kKB + 8 * h];
+                        u32x4 vh, vl;
+                        split_product_f16x4(ph, pl, yh, yl, vh, vl);
+                        const f16x8 ch = __builtin_bit_cast(f16x8, vh), cl = __builtin_bit_cast(f16x8, vl);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0h, ah, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0h, ch, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0l, ah, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0l, ch, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0h, al, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0h, cl, acc1, 0, 0, 0);
+                    } else {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0h, ah, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0l, ah, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0h, al, acc0, 0, 0, 0);
+                    }
+                    dirty = true;
+                    continue;
+                }
                 // one column tile after the other, each a chain of three MFMAs on its own accumulator (requesting the B
                 // fragments ahead of the packed arithmetic, alternating the two chains, or both: no gain, profiles/r04_experiments.md)
                 if (hv & 1) {
@@ -720,7 +853,7 @@ int launch_plane_absmax(const Geom &g_halo, const PlanLayout &L_halo, const void
     return 0;
 }
 
-template <int W, bool OWNED>
+template <int W, bool OWNED, bool PAIR>
 static int launch_mfma_t(const Geom &g, const PlanLayout &L, const void *plan, const int *to, const float *spos,
                          const float *xr, const float *xs, const unsigned *xmax, int64_t n, int64_t Cr, int64_t plane0,
                          int64_t nplanes, float *grid, hipStream_t stream)
@@ -733,31 +866,40 @@ static int launch_mfma_t(const Geom &g, const PlanLayout &L, const void *plan, c
     if (nsets < 1) nsets = 1;
     const int nsegm = seg_base_runs(n, nsets, pencils, g.M, device_cu_count());
     const int seg_slabs = (g.M + nsegm - 1) / nsegm;
-    const dim3 blocks((unsigned)(pencils * nsegm), (unsigned)nplanes);
+    // y grid: planes, or the pair slots the chunk of planes touches (paired variant)
+    int64_t ny = nplanes;
+    if (PAIR) {
+        const int64_t P = (Cr + 1) / 2, last = plane0 + nplanes - 1;
+        const int64_t s0 = (plane0 / Cr) * P + (plane0 % Cr) / 2, s1 = (last / Cr) * P + (last % Cr) / 2;
+        ny = s1 - s0 + 1;
+    }
+    const dim3 blocks((unsigned)(pencils * nsegm), (unsigned)ny);
     static DeviceOnce attr_done;  // one workgroup per CU: the double-buffered operands take most of the 160 KB LDS
     if (attr_done.first_use()) {
-        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)spread_mfma_kernel<W, false, OWNED>,
+        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)spread_mfma_kernel<W, false, OWNED, PAIR>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MfmaLds<W>)));
-        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)spread_mfma_kernel<W, true, OWNED>,
+        NFFT_HIP_CHECK(hipFuncSetAttribute((const void *)spread_mfma_kernel<W, true, OWNED, PAIR>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MfmaLds<W>)));
         attr_done.mark();
     }
     const char *base = (const char *)plan;
     const int4 *work = (const int4 *)(base + L.off_work), *sorted = work + L.work_head + L.work_cap;
     int *const status = device_status_block();
-    hipLaunchKernelGGL((spread_mfma_kernel<W, false, OWNED>), blocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to,
-                       spos, xr, xs, L.cap, xmax, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, work, sorted, WorkTickets{nullptr, 0u}, status);
+    hipLaunchKernelGGL((spread_mfma_kernel<W, false, OWNED, PAIR>), blocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to,
+                       spos, xr, xs, L.cap, xmax, (int)Cr, (int)plane0, (int)nplanes, grid, seg_slabs, nsegm, work, sorted,
+                       WorkTickets{nullptr, 0u}, status);
     // the persistent launch over the work list (unbalanced plans; its workgroups leave at once otherwise); entries are
     // handed out by tickets when the launch's planes fit its share of the ticket ring, else round robin
-    const WorkTickets tickets{nplanes <= kTicketPlanes ? device_ticket_ring() : nullptr, next_launch_number()};
-    const dim3 oblocks(work_list_workgroups(n, nsets, pencils, nsegm, device_cu_count()), (unsigned)nplanes);
-    hipLaunchKernelGGL((spread_mfma_kernel<W, true, OWNED>), oblocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to,
-                       spos, xr, xs, L.cap, xmax, (int)Cr, (int)plane0, grid, seg_slabs, nsegm, work, sorted, tickets, status);
+    const WorkTickets tickets{ny <= kTicketPlanes ? device_ticket_ring() : nullptr, next_launch_number()};
+    const dim3 oblocks(work_list_workgroups(n, nsets, pencils, nsegm, device_cu_count()), (unsigned)ny);
+    hipLaunchKernelGGL((spread_mfma_kernel<W, true, OWNED, PAIR>), oblocks, dim3(kMfmaThreads), sizeof(MfmaLds<W>), stream, g, to,
+                       spos, xr, xs, L.cap, xmax, (int)Cr, (int)plane0, (int)nplanes, grid, seg_slabs, nsegm, work, sorted, tickets,
+                       status);
     NFFT_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-template <bool OWNED>
+template <bool OWNED, bool PAIR>
 static int launch_mfma_w(const Geom &g, const PlanLayout &L, const void *plan, const float *xr, const float *xs,
                          const unsigned *xmax, int64_t n, int64_t Cr, int64_t plane0, int64_t nplanes, float *grid,
                          hipStream_t stream)
@@ -766,13 +908,13 @@ static int launch_mfma_w(const Geom &g, const PlanLayout &L, const void *plan, c
     const int *to = (const int *)(base + L.off_offsets);
     const float *spos = (const float *)(base + L.off_spos);
     switch (g.m) {
-    case 1: return launch_mfma_t<4, OWNED>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
-    case 2: return launch_mfma_t<6, OWNED>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
-    case 3: return launch_mfma_t<8, OWNED>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
-    case 4: return launch_mfma_t<10, OWNED>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
-    case 5: return launch_mfma_t<12, OWNED>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
-    case 6: return launch_mfma_t<14, OWNED>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
-    case 7: return launch_mfma_t<16, OWNED>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
+    case 1: return launch_mfma_t<4, OWNED, PAIR>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
+    case 2: return launch_mfma_t<6, OWNED, PAIR>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
+    case 3: return launch_mfma_t<8, OWNED, PAIR>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
+    case 4: return launch_mfma_t<10, OWNED, PAIR>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
+    case 5: return launch_mfma_t<12, OWNED, PAIR>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
+    case 6: return launch_mfma_t<14, OWNED, PAIR>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
+    case 7: return launch_mfma_t<16, OWNED, PAIR>(g, L, plan, to, spos, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
     }
     set_error("matrix-core spreading supports cutoff 1..7");
     return 1;
@@ -792,8 +934,13 @@ int launch_spread_mfma(const Geom &g, const PlanLayout &L, const void *plan, con
         if (g.owned) NFFT_HIP_CHECK(hipMemsetAsync(grid, 0, (size_t)(nplanes * g.cells * 4), stream));
         return 0;
     }
-    return g.owned ? launch_mfma_w<true>(g, L, plan, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream)
-                   : launch_mfma_w<false>(g, L, plan, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
+    if (g.pair && Cr < 2) {
+        set_error("Input mismatch: a plan of the paired owned tiling (num_columns >= 2) used with one real column");
+        return 1;
+    }
+    return g.pair    ? launch_mfma_w<true, true>(g, L, plan, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream)
+           : g.owned ? launch_mfma_w<true, false>(g, L, plan, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream)
+                     : launch_mfma_w<false, false>(g, L, plan, xr, xs, xmax, n, Cr, plane0, nplanes, grid, stream);
 }
 
 } // namespace nfft
