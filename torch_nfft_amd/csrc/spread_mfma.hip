@@ -264,9 +264,6 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     // full time instead of idling through the accumulation)
     constexpr int NOWN = W <= 12 ? 12 : 16;
     const bool owner = wave < NOWN;
-#ifdef NFFT_BUILDER_PRIO
-    if (!owner) __builtin_amdgcn_s_setprio(NFFT_BUILDER_PRIO);
-#endif
     const int z_lo = OWNED ? sb : sb - m;  // first plane any owner holds
     int myz = z_lo + (((wave - z_lo) % NOWN) + NOWN) % NOWN;
     // staging threads: the first two non-owner waves if there are any, else waves 0 and 1
@@ -537,9 +534,6 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
     [[maybe_unused]] int tasks_taken = 0;  // (trace builds only)
     auto build_tasks = [&](const MfmaStage &S, MfmaOps<W> &O, const int nkb, int *counter) {
         tasks_taken = 0;
-#ifdef NFFT_BUILD_PRIO
-        if (owner) __builtin_amdgcn_s_setprio(NFFT_BUILD_PRIO);
-#endif
         while (true) {
             // all 64 lanes add 1 (the compiler folds this into one ds_add of 64 per wave): the counter runs in units of
             // 64, lane 0 sees the wave's base value
@@ -635,9 +629,6 @@ spread_mfma_kernel(const Geom g, const int *__restrict__ tile_offsets, const flo
                 O.slab[j] = sl;
             }
         }
-#ifdef NFFT_BUILD_PRIO
-        if (owner) __builtin_amdgcn_s_setprio(0);
-#endif
     };
 
     // ---- every wave adds the K-blocks that reach its plane -------------------------------------------------
