@@ -277,8 +277,16 @@ template <bool COMMON>
 __global__ void __launch_bounds__(kSortThreads)
 sort1_scatter_kernel(Geom g_in, const float *__restrict__ pos, const int64_t *__restrict__ batch, int64_t n, int64_t B,
                      int npencils, int nblocks, int block_points, const int *__restrict__ hscan, const unsigned short *__restrict__ key1,
-                     float4 *__restrict__ tmp, const unsigned long long *__restrict__ seal_part, unsigned long long *__restrict__ seal)
+                     float4 *__restrict__ tmp, const unsigned long long *__restrict__ seal_part, unsigned long long *__restrict__ seal,
+                     int *__restrict__ final_offsets, int *__restrict__ final_perm, float *__restrict__ final_spos)
 {
+    // 1-D / 2-D plans have ONE plan bin per first-level bin (no axis-0 bins, no sub-blocks, no column groups): this pass
+    // then writes the plan itself -- offsets, permutation, tile-ordered points -- and the second level (two launches that
+    // only copied the records) does not run
+    const bool final_pass = !COMMON && final_offsets != nullptr;
+    if (final_pass && blockIdx.x == 0) {
+        for (int i = threadIdx.x; i <= npencils; i += kSortThreads) final_offsets[i] = hscan[(int64_t)i * nblocks];
+    }
     if (seal && blockIdx.x == 0) {
         // the plan's seal: sum of the count pass's per-slice shares; the rest of the seal block (accumulators and arrival
         // counters of verifications) starts at zero
@@ -326,6 +334,12 @@ sort1_scatter_kernel(Geom g_in, const float *__restrict__ pos, const int64_t *__
             }
             for (int r = 0; r < k; ++r) {
                 const int slot = atomicAdd(&lds_cur[bins[r]], 1);
+                if (final_pass) {
+                    final_perm[slot] = (int)i;
+                    final_spos[(int64_t)slot * g.dim] = c0[q];
+                    if (g.dim > 1) final_spos[(int64_t)slot * g.dim + 1] = c1[q];
+                    continue;
+                }
                 tmp[slot] = make_float4(c0[q], c1[q], c2[q], __int_as_float((int)i));
             }
         }
@@ -778,8 +792,15 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
                            npencils, nblocks, (int)L.block_points, hist, key1, seal ? (unsigned long long *)(base + L.off_sealpart) : nullptr,
                            device_status_block());
         if (int rc = exclusive_scan(hist, hscan, items, base + L.off_scan, L.scan_bytes, stream)) return rc;
+        // (1-D / 2-D: the first level is the whole sort)
+        const bool one_level = g.dim < 3 && g.l1seg == 1 && (int64_t)g.l1bins * g.SB * g.CG == 1 && L.ntiles == L.npencils;
         hipLaunchKernelGGL(common ? sort1_scatter_kernel<true> : sort1_scatter_kernel<false>, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
-                           npencils, nblocks, (int)L.block_points, hscan, key1, tmp, (const unsigned long long *)(base + L.off_sealpart), seal);
+                           npencils, nblocks, (int)L.block_points, hscan, key1, tmp, (const unsigned long long *)(base + L.off_sealpart), seal,
+                           one_level ? offsets : nullptr, perm, spos);
+        if (one_level) {
+            NFFT_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
         int *hist2 = (int *)(base + L.off_hist2);
         const size_t lds2 = (size_t)g.l1bins * g.SB * g.CG * 4;
         hipLaunchKernelGGL(common ? sort2_count_kernel<true> : sort2_count_kernel<false>, dim3(npencils, kSort2Parts), dim3(kSortThreads), lds2, stream, g, nblocks,
@@ -887,7 +908,9 @@ points_seal_kernel(const float *__restrict__ pos, const int64_t *__restrict__ ba
 static int seal_launch(const float *pos, const int64_t *batch, int64_t n, int dim, unsigned long long *acc,
                        const unsigned long long *expect, unsigned *arrivals, hipStream_t stream)
 {
-    int64_t blocks = (n + kSealThreads * 16 - 1) / (kSealThreads * 16);  // >= 16 points per thread
+    // >= 4 points per thread (one round of loads in flight: a small input is a latency chain, 9 us -> 5 for 10^5 points);
+    // big inputs are capped at 512 workgroups, i.e. many points per thread
+    int64_t blocks = (n + kSealThreads * 4 - 1) / (kSealThreads * 4);
     blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
     hipLaunchKernelGGL(points_seal_kernel, dim3((unsigned)blocks), dim3(kSealThreads), 0, stream, pos, batch, n, dim, acc, expect,
                        arrivals, device_status_block());
