@@ -278,13 +278,18 @@ __global__ void __launch_bounds__(kSortThreads)
 sort1_scatter_kernel(Geom g_in, const float *__restrict__ pos, const int64_t *__restrict__ batch, int64_t n, int64_t B,
                      int npencils, int nblocks, int block_points, const int *__restrict__ hscan, const unsigned short *__restrict__ key1,
                      float4 *__restrict__ tmp, const unsigned long long *__restrict__ seal_part, unsigned long long *__restrict__ seal,
-                     int *__restrict__ final_offsets, int *__restrict__ final_perm, float *__restrict__ final_spos)
+                     int *__restrict__ final_offsets, int *__restrict__ final_perm, float *__restrict__ final_spos,
+                     const int *__restrict__ hist_raw)
 {
     // 1-D / 2-D plans have ONE plan bin per first-level bin (no axis-0 bins, no sub-blocks, no column groups): this pass
     // then writes the plan itself -- offsets, permutation, tile-ordered points -- and the second level (two launches that
     // only copied the records) does not run
     const bool final_pass = !COMMON && final_offsets != nullptr;
-    if (final_pass && blockIdx.x == 0) {
+    // ... and for a small table of counts (hist_raw != nullptr: <= 16 384 of them) every workgroup scans it itself, so that
+    // the scan launch between the two passes is gone as well: cursor of bin p in this slice = points of the bins before p
+    // (all slices) + points of bin p in the slices before this one
+    const bool local_scan = final_pass && hist_raw != nullptr;
+    if (final_pass && !local_scan && blockIdx.x == 0) {
         for (int i = threadIdx.x; i <= npencils; i += kSortThreads) final_offsets[i] = hscan[(int64_t)i * nblocks];
     }
     if (seal && blockIdx.x == 0) {
@@ -304,7 +309,47 @@ sort1_scatter_kernel(Geom g_in, const float *__restrict__ pos, const int64_t *__
     Geom g = g_in;
     if constexpr (COMMON) { g.dim = 3; g.owned = 0; }
     extern __shared__ int lds_cur[];
-    for (int i = threadIdx.x; i < npencils; i += kSortThreads) lds_cur[i] = hscan[(int64_t)i * nblocks + blockIdx.x];
+    if (local_scan) {
+        int *const row = lds_cur + npencils;  // [npencils] points per bin over all slices (LDS: 2 * npencils ints)
+        for (int i = threadIdx.x; i < npencils; i += kSortThreads) { lds_cur[i] = 0; row[i] = 0; }
+        __syncthreads();
+        // G threads per bin (a power of two, 512 / bins at most), each sums every G-th slice: G LDS atomics per bin
+        int G = 1;
+        while (2 * G * npencils <= kSortThreads && G < 64) G *= 2;
+        const int sub = threadIdx.x & (G - 1);
+        for (int p = threadIdx.x / G; p < npencils; p += kSortThreads / G) {
+            int all = 0, before = 0;
+            for (int bl = sub; bl < nblocks; bl += G) {
+                const int c = hist_raw[p * nblocks + bl];
+                all += c;
+                before += bl < (int)blockIdx.x ? c : 0;
+            }
+            if (all) atomicAdd(&row[p], all);
+            if (before) atomicAdd(&lds_cur[p], before);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {  // exclusive scan of the bin totals, one wave
+            int carry = 0;
+            for (int base = 0; base < npencils; base += 64) {
+                const int idx = base + threadIdx.x;
+                const int tot = idx < npencils ? row[idx] : 0;
+                int incl = tot;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int t = __shfl_up(incl, off);
+                    if ((int)threadIdx.x >= off) incl += t;
+                }
+                if (idx < npencils) {
+                    const int excl = carry + incl - tot;
+                    lds_cur[idx] += excl;
+                    if (blockIdx.x == 0) final_offsets[idx] = excl;
+                }
+                carry += __shfl(incl, 63);
+            }
+            if (blockIdx.x == 0 && threadIdx.x == 0) final_offsets[npencils] = carry;
+        }
+    } else {
+        for (int i = threadIdx.x; i < npencils; i += kSortThreads) lds_cur[i] = hscan[(int64_t)i * nblocks + blockIdx.x];
+    }
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * block_points;
     const int64_t hi = min(n, lo + block_points);
@@ -791,12 +836,15 @@ int launch_plan_points(const Geom &g, const PlanLayout &L, const float *pos, con
         hipLaunchKernelGGL(common ? sort1_count_kernel<true> : sort1_count_kernel<false>, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
                            npencils, nblocks, (int)L.block_points, hist, key1, seal ? (unsigned long long *)(base + L.off_sealpart) : nullptr,
                            device_status_block());
-        if (int rc = exclusive_scan(hist, hscan, items, base + L.off_scan, L.scan_bytes, stream)) return rc;
-        // (1-D / 2-D: the first level is the whole sort)
+        // (1-D / 2-D: the first level is the whole sort; a small table of counts is scanned inside the scatter pass)
         const bool one_level = g.dim < 3 && g.l1seg == 1 && (int64_t)g.l1bins * g.SB * g.CG == 1 && L.ntiles == L.npencils;
-        hipLaunchKernelGGL(common ? sort1_scatter_kernel<true> : sort1_scatter_kernel<false>, dim3(nblocks), dim3(kSortThreads), lds1, stream, g, pos, batch, n, B,
+        const bool local_scan = one_level && items <= 16384;
+        if (!local_scan)
+            if (int rc = exclusive_scan(hist, hscan, items, base + L.off_scan, L.scan_bytes, stream)) return rc;
+        hipLaunchKernelGGL(common ? sort1_scatter_kernel<true> : sort1_scatter_kernel<false>, dim3(nblocks), dim3(kSortThreads),
+                           local_scan ? 2 * lds1 : lds1, stream, g, pos, batch, n, B,
                            npencils, nblocks, (int)L.block_points, hscan, key1, tmp, (const unsigned long long *)(base + L.off_sealpart), seal,
-                           one_level ? offsets : nullptr, perm, spos);
+                           one_level ? offsets : nullptr, perm, spos, local_scan ? hist : nullptr);
         if (one_level) {
             NFFT_HIP_CHECK(hipGetLastError());
             return 0;
