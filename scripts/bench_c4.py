@@ -1,10 +1,11 @@
-"""Developer tool: timing of a C4-shaped problem (batched point sets x many coefficient columns) on one GPU."""
+"""Developer tool: timing + stage split of a batched problem (B point sets x C coefficient columns, NPER points per set, bandwidth NB,
+cutoff MC from the environment; default: a C4-shaped one) on one GPU."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 import torch_nfft_amd as tn
 from torch_nfft_amd import _lib, ops
-N, m, B, C, n_per = 128, 4, int(os.environ.get("B", 4)), int(os.environ.get("C", 64)), int(os.environ.get("NPER", 250_000))
+N, m, B, C, n_per = int(os.environ.get("NB", 128)), int(os.environ.get("MC", 4)), int(os.environ.get("B", 4)), int(os.environ.get("C", 64)), int(os.environ.get("NPER", 250_000))
 gen = torch.Generator(device="cuda").manual_seed(5)
 pos = torch.rand((B * n_per, 3), generator=gen, device="cuda") - 0.5
 batch = torch.arange(B * n_per, device="cuda") // n_per
@@ -17,7 +18,7 @@ for _ in range(2): step()
 torch.cuda.synchronize()
 _lib.profile_enable(True); _lib.profile_collect()
 t0 = time.perf_counter()
-K = 5
+K = int(os.environ.get("K", 5))
 for _ in range(K): step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K

@@ -291,9 +291,25 @@ struct PlanSet {
 };
 // Geometry of a problem's (halo-tiling) plan.  The column-group order of the plan (common.h Geom::CG) pays where the
 // streamed gather runs, i.e. for big work items; below that it only costs sorting time (+0.03 ms at 10^6 points).
+// The 64^3 grid (N = 32, the reference's default bandwidth: torch_nfft/nfft.py:150-156) is 3 x 2 pencils of the wide tiling,
+// two of which hold 70 % of the cells: the matrix-core kernels' work items (ranges of slabs of one pencil, at most 16 pieces
+// per range) cannot spread a dense point set over 256 CUs -- 10^6 points, m = 3: 1.46 ms per adjoint + forward against 0.51
+// with the narrow tiling, whose LDS kernels share a (pencil, segment) among up to 32 workgroups.  What the narrow path pays is
+// one LDS atomic per window tap: it wins for the narrow windows and for few taps in total (sweep: profiles/r04_experiments.md).
+// NFFT_HIP_SMALL_NARROW=0 keeps the wide tiling.
+bool prefer_narrow(const nfft_hip_problem *p)
+{
+    static const bool off = [] {
+        const char *env = std::getenv("NFFT_HIP_SMALL_NARROW");
+        return env && env[0] == '0';
+    }();
+    if (off || p->dim != 3 || p->N != 32) return false;
+    const double W = 2.0 * (double)p->m + 2.0;
+    return p->m <= 3 || (double)p->num_points * W * W * W <= 6.0e7;
+}
 Geom problem_geom(const nfft_hip_problem *p)
 {
-    Geom g = make_geom(p->dim, p->N, p->m);
+    Geom g = make_geom(p->dim, p->N, p->m, false, false, prefer_narrow(p));
     if (g.CG > 1 && !stream_items(p->num_points, p->batch_size, device_cu_count())) g.CG = 1;
     return g;
 }
@@ -354,7 +370,7 @@ int validate(const nfft_hip_problem *p)
     if (p->num_points >= (int64_t(1) << 31)) { set_error("Input mismatch: too many points"); return NFFT_HIP_EINVAL; }
     {
         // the point plan indexes its (point set, tile) bins with 32-bit integers
-        const Geom g = make_geom((int)p->dim, (int)p->N, (int)p->m);
+        const Geom g = problem_geom(p);
         if ((double)g.tiles_per_batch * (double)p->batch_size * (double)g.SB >= 2.0e9) {
             set_error("Input mismatch: too many point sets for this grid (plan bins exceed 2^31)");
             return NFFT_HIP_EINVAL;

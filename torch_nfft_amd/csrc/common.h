@@ -123,7 +123,7 @@ unsigned next_launch_number();             // api.hip: process-wide, never 0
 bool work_list_forced();       // api.hip: NFFT_HIP_WORK_LIST=1 runs every wide plan from its work list
 bool column_groups_enabled();  // api.hip: NFFT_HIP_COLGROUPS=0 turns the column-group order of the plan off
 
-inline Geom make_geom(int dim, int64_t N, int64_t m, bool owned = false, bool pair = false)
+inline Geom make_geom(int dim, int64_t N, int64_t m, bool owned = false, bool pair = false, bool narrow = false)
 {
     Geom g;
     g.dim = dim;
@@ -139,7 +139,8 @@ inline Geom make_geom(int dim, int64_t N, int64_t m, bool owned = false, bool pa
         if (live) g.cells *= g.M;
     }
     // 16 waves hold 16 resident planes: the axis-0 window (2m+2 planes) has to fit
-    g.wide = dim == 3 && spread_mode() == kSpreadMfma && g.M >= 64 && g.M <= 1024 && g.W <= 16;
+    // (`narrow`: the caller knows the problem is better served by the narrow tiling and its LDS kernels: api.hip prefer_narrow)
+    g.wide = dim == 3 && spread_mode() == kSpreadMfma && g.M >= 64 && g.M <= 1024 && g.W <= 16 && !narrow;
     // at least two tiles per axis, so that a window never touches the same tile from both sides of the torus
     g.owned = owned && g.wide && g.M >= 128 && g.M % 64 == 0;
     g.pair = g.owned && pair;
@@ -409,6 +410,11 @@ inline int seg_base_runs(int64_t n, int64_t nsets, int64_t pencils, int M, int n
     int64_t r = (int64_t)(avg / (double)seg_target_points(n, nsets, ncu) + 0.5);
     const int64_t lo = (M + 127) / 128, hi = M / 32 > lo ? M / 32 : lo;  // a range holds 32 .. 128 slabs
     r = r < lo ? lo : (r > hi ? hi : r);
+    // Small problems: a range is ONE workgroup's serial chain of chunks, so few long ranges leave most CUs idle behind a long
+    // chain (N = 64, 2e4 points: 18 workgroups of 128 slabs took 0.26 ms in the gather, 72 of 32 slabs 0.08) -- as many ranges as
+    // the CUs can take in one round
+    const int64_t groups = (nsets > 0 ? nsets : 1) * (pencils > 0 ? pencils : 1);
+    while (r < hi && groups * (r + 1) <= (ncu > 0 ? ncu : 256)) ++r;
     return (int)(r > kSegMax ? kSegMax : r);
 }
 // Workgroups of the persistent launch over a plan's work list: one per CU, but no more than a point set can have entries
