@@ -623,13 +623,7 @@ def test_columns_of_very_different_magnitude(tn):
 
 # ----------------------------------------------------------------------------- owner-computes spreading (sparse inputs)
 
-@pytest.mark.parametrize("m,Cr", [(1, 2), (4, 2), (7, 2), (4, 1), (4, 3), (2, 5), (7, 3)])
-def test_owned_spreading_stage_tile_borders(tn, m, Cr):
-    """Sparse 3-D problems spread by owner-computes (a plan entry per touched tile, plain stores; one column: 32 x 64
-    tiles, one sweep of the points per column; two or more: 32 x 32 tiles, one sweep per PAIR of columns -- an odd column
-    count leaves every point set's last column to a sweep of its own): points on tile corners and edges, on the torus
-    boundary, in neighbouring point sets -- the spread grid against the oracle's gridding, written completely (the grid is
-    pre-filled with NaN) and bitwise reproducible."""
+def _owned_stage_case(m, Cr):
     import ctypes
     from torch_nfft_amd import _lib
     lib = _lib.load()
@@ -665,6 +659,26 @@ def test_owned_spreading_stage_tile_borders(tn, m, Cr):
     grid2 = torch.full_like(grid, float("nan"))
     _lib.check(lib.nfft_hip_spread(ctypes.byref(prob), p(plan), p(xt), Cr, p(grid2), p(scratch), s))
     assert torch.equal(grid, grid2)
+
+
+@pytest.mark.parametrize("m,Cr", [(1, 2), (4, 2), (7, 2), (4, 1), (4, 3), (2, 5), (7, 3)])
+def test_owned_spreading_stage_tile_borders(tn, m, Cr):
+    """Sparse 3-D problems spread by owner-computes (a plan entry per touched tile, plain stores; one column: 32 x 64
+    tiles, one sweep of the points per column; two or more: 32 x 32 tiles, one sweep per PAIR of columns -- an odd column
+    count leaves every point set's last column to a sweep of its own): points on tile corners and edges, on the torus
+    boundary, in neighbouring point sets -- the spread grid against the oracle's gridding, written completely (the grid is
+    pre-filled with NaN) and bitwise reproducible.  (A single column on a 128^3 grid takes the scatter variant by default
+    since round 4: that case runs in a process that forces the owned one.)"""
+    if Cr >= 2:
+        return _owned_stage_case(m, Cr)
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import sys; sys.path[:0] = [%r, %r]; import test_gpu_parity as t; t._owned_stage_case(%d, %d); print('CASE OK')" % (
+        root, os.path.join(root, "tests"), m, Cr)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NFFT_HIP_OWNED="1"), capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0 and "CASE OK" in out.stdout, out.stderr[-3000:] + out.stdout[-1000:]
 
 
 @pytest.mark.parametrize("env_extra", [{"NFFT_HIP_OWNED": "0"}, {"NFFT_HIP_OWNED": "0", "NFFT_HIP_STREAM_MIN": "1"}],

@@ -320,6 +320,9 @@ PlanSet plan_set(const nfft_hip_problem *p)
     ps.L = plan_layout(ps.g, p->num_points, p->batch_size);
     ps.owned = choose_owned(p->dim, p->N, p->m, p->num_points, p->batch_size,
                             (p->flags & NFFT_HIP_POINTS_IN_QUARTER_BALL) ? 0.125 : 1.0);
+    // (a single column on a 128^3 grid: what the owner-computes kernel saves -- 10 us of zero-fill, the atomics of a few
+    // thousand K-blocks -- is less than its second sort costs: plan 0.074 against 0.038 ms at 2e4 points, round 4)
+    if (p->N < 128 && p->num_columns < 2 && owned_override() < 0) ps.owned = false;
     ps.go = ps.g;
     ps.Lo = ps.L;
     ps.off_own = 0;
