@@ -437,7 +437,7 @@ def main():
         # launch): the matrix-core kernel for 3-D grids of 64^3 and up with m <= 7, else spread_kernel
         W = 2 * m + 2
         mfma = d == 3 and M >= 64 and W <= 16 and os.environ.get("NFFT_HIP_SPREAD", "m")[:1] not in ("l", "r")
-        kname = "spread_mfma_kernel<%d, false, false>" % W if mfma else "spread_kernel<%d,%d>" % (d, W)
+        kname = "spread_mfma_kernel<%d, false, false, false>" % W if mfma else "spread_kernel<%d,%d>" % (d, W)
         # matrix flops the kernel issues per tap row: 3 MFMA terms x 2 x 32 x 64 x 16 per (plane, 16 points) -- half of it for
         # a K-block whose windows lie in one 32-column half of the tile (the plan orders slabs by column group when the
         # work items are big; K-blocks that straddle a group boundary do both halves, so this is a slight underestimate)
