@@ -7,6 +7,9 @@ import torch_nfft_amd as tn
 gen = torch.Generator(device="cuda").manual_seed(3)
 cases = [(N, m, n, B) for N in (32, 64) for m in (2, 3, 4, 6) for (n, B) in ((20_000, 1), (100_000, 1), (1_000_000, 1), (800_000, 8))]
 cases += [(48, 3, 100_000, 1), (48, 4, 800_000, 8)]
+if os.environ.get("SWEEP") == "fine":
+    cases = [(32, m, n * B, B) for m in (4, 5) for B in (1, 4) for n in (50_000, 200_000, 500_000, 1_000_000)]
+    cases += [(64, m, n * B, B) for m in (2, 3) for B in (4, 8, 16) for n in (20_000, 100_000)]
 for N, m, n, B in cases:
     pos = torch.rand((n, 3), generator=gen, device="cuda") - 0.5
     x = torch.rand((n,), generator=gen, device="cuda")

@@ -295,7 +295,7 @@ struct PlanSet {
 // two of which hold 70 % of the cells: the matrix-core kernels' work items (ranges of slabs of one pencil, at most 16 pieces
 // per range) cannot spread a dense point set over 256 CUs -- 10^6 points, m = 3: 1.46 ms per adjoint + forward against 0.51
 // with the narrow tiling, whose LDS kernels share a (pencil, segment) among up to 32 workgroups.  What the narrow path pays is
-// one LDS atomic per window tap: it wins for the narrow windows and for few taps in total (sweep: profiles/r04_experiments.md).
+// one LDS atomic per window tap: it wins for the narrow windows and for few points (sweep: profiles/r04_experiments.md).
 // NFFT_HIP_SMALL_NARROW=0 keeps the wide tiling.
 bool prefer_narrow(const nfft_hip_problem *p)
 {
@@ -303,9 +303,13 @@ bool prefer_narrow(const nfft_hip_problem *p)
         const char *env = std::getenv("NFFT_HIP_SMALL_NARROW");
         return env && env[0] == '0';
     }();
-    if (off || p->dim != 3 || p->N != 32) return false;
-    const double W = 2.0 * (double)p->m + 2.0;
-    return p->m <= 3 || (double)p->num_points * W * W * W <= 6.0e7;
+    if (off || p->dim != 3) return false;
+    // 128^3 grid, narrow window, many point sets: every (set, pencil) is a chain of nearly empty K-blocks (2e4 points per set:
+    // 9 per pencil and slab), and from eight sets up there are more chains than CUs -- 16 sets x 2e4 points, m = 2: 1.17 ms
+    // against 0.90 on the narrow tiling; with four sets the matrix-core path is still ahead (0.42 against 0.45)
+    if (p->N == 64) return p->m <= 3 && p->batch_size >= 8;
+    if (p->N != 32) return false;
+    return p->m <= 3 || p->num_points <= 30000;
 }
 Geom problem_geom(const nfft_hip_problem *p)
 {
@@ -323,6 +327,7 @@ PlanSet plan_set(const nfft_hip_problem *p)
     // (a single column on a 128^3 grid: what the owner-computes kernel saves -- 10 us of zero-fill, the atomics of a few
     // thousand K-blocks -- is less than its second sort costs: plan 0.074 against 0.038 ms at 2e4 points, round 4)
     if (p->N < 128 && p->num_columns < 2 && owned_override() < 0) ps.owned = false;
+    if (!ps.g.wide) ps.owned = false;  // (the narrow tiling was preferred: no matrix-core spreading, no owned plan)
     ps.go = ps.g;
     ps.Lo = ps.L;
     ps.off_own = 0;

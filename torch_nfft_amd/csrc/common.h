@@ -411,8 +411,9 @@ inline int seg_base_runs(int64_t n, int64_t nsets, int64_t pencils, int M, int n
     const int64_t lo = (M + 127) / 128, hi = M / 32 > lo ? M / 32 : lo;  // a range holds 32 .. 128 slabs
     r = r < lo ? lo : (r > hi ? hi : r);
     // Small problems: a range is ONE workgroup's serial chain of chunks, so few long ranges leave most CUs idle behind a long
-    // chain (N = 64, 2e4 points: 18 workgroups of 128 slabs took 0.26 ms in the gather, 72 of 32 slabs 0.08) -- as many ranges as
-    // the CUs can take in one round
+    // chain (N = 64, 2e4 points: 18 workgroups of 128 slabs took 0.26 ms in the gather, 72 of 32 slabs 0.08):
+    // as many ranges as the CUs take in ONE round (a count chosen by a cost model, rounds x (slabs + halo), also cut the ranges
+    // of problems that fill the CUs more than once: measured slower, N = 64, four sets of 10^5 points 0.484 -> 0.532 ms)
     const int64_t groups = (nsets > 0 ? nsets : 1) * (pencils > 0 ? pencils : 1);
     while (r < hi && groups * (r + 1) <= (ncu > 0 ? ncu : 256)) ++r;
     return (int)(r > kSegMax ? kSegMax : r);
