@@ -23,6 +23,8 @@ for seed in range(first, first + int(sys.argv[1])):
     rf = nfft_ref.nfft_forward(c["xh"], c["pos"], c["batch"], m=c["m"], real_output=c["real_fwd"])
     ea, ef = rel(ya.cpu().numpy(), ra), rel(yf.cpu().numpy(), rf)
     worst = max(worst, ea, ef)
+    if max(ea, ef) > 2e-6:  # (worth a look: the matrix-core and LDS paths are normally at 1e-7 ... 1e-6)
+        print("NOTE seed", seed, "d=%d N=%d m=%d B=%d n=%d cols=%s" % (c["d"], c["N"], c["m"], c["B"], c["n"], c["cols"]), ea, ef, flush=True)
     if not (ea < 2e-5 and ef < 2e-5):
         bad += 1
         print("FAIL seed", seed, "d=%d N=%d m=%d B=%d n=%d cols=%s" % (c["d"], c["N"], c["m"], c["B"], c["n"], c["cols"]), ea, ef, flush=True)
