@@ -307,7 +307,9 @@ bool prefer_narrow(const nfft_hip_problem *p)
     // 128^3 grid, narrow window, many point sets: every (set, pencil) is a chain of nearly empty K-blocks (2e4 points per set:
     // 9 per pencil and slab), and from eight sets up there are more chains than CUs -- 16 sets x 2e4 points, m = 2: 1.17 ms
     // against 0.90 on the narrow tiling; with four sets the matrix-core path is still ahead (0.42 against 0.45)
-    if (p->N == 64) return p->m <= 3 && p->batch_size >= 8;
+    // (one column only: with eight columns and 2e4 points per set the paired owner-computes spreading is 5x ahead of the LDS
+    // kernel, 0.24 against 1.28 ms)
+    if (p->N == 64) return p->m <= 3 && p->batch_size >= 8 && p->num_columns == 1;
     if (p->N != 32) return false;
     return p->m <= 3 || p->num_points <= 30000;
 }
