@@ -765,6 +765,9 @@ static int launch_segment_split(const Geom &g, const PlanLayout &L, int64_t n, i
 // Exclusive prefix sum of up to kSmallScanItems ints in ONE workgroup (small problems: hipCUB's device scan is two launches,
 // ~5 us of host time each, for a few thousand counters).  out[i] = in[0] + ... + in[i - 1].
 constexpr int kSmallScanItems = 1 << 16;
+// IPT consecutive items per thread and round: 4 for a few thousand items (one round), 16 beyond (a round is three barriers and a
+// serial sum over the waves, ~5 us: 23 500 items took 31 us in rounds of 4 096 -- more than hipCUB's two launches)
+template <int IPT>
 __global__ void __launch_bounds__(1024) small_scan_kernel(const int *__restrict__ in, int *__restrict__ out, int items)
 {
     __shared__ int wave_sums[16];
@@ -772,13 +775,15 @@ __global__ void __launch_bounds__(1024) small_scan_kernel(const int *__restrict_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < items; base += 4096) {
-        // four consecutive items per thread
-        const int i0 = base + 4 * (int)threadIdx.x;
-        int v[4];
+    for (int base = 0; base < items; base += 1024 * IPT) {
+        const int i0 = base + IPT * (int)threadIdx.x;
+        int v[IPT];
+        int mine = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = i0 + k < items ? in[i0 + k] : 0;
-        const int mine = v[0] + v[1] + v[2] + v[3];
+        for (int k = 0; k < IPT; ++k) {
+            v[k] = i0 + k < items ? in[i0 + k] : 0;
+            mine += v[k];
+        }
         int incl = mine;
         for (int off = 1; off < 64; off <<= 1) {
             const int t = __shfl_up(incl, off);
@@ -790,12 +795,12 @@ __global__ void __launch_bounds__(1024) small_scan_kernel(const int *__restrict_
         for (int w = 0; w < wave; ++w) before += wave_sums[w];
         int run = before + incl - mine;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < IPT; ++k) {
             if (i0 + k < items) out[i0 + k] = run;
             run += v[k];
         }
         __syncthreads();
-        if (threadIdx.x == 1023) carry_s = run;  // (the last thread's running sum: everything up to base + 4096)
+        if (threadIdx.x == 1023) carry_s = run;  // (the last thread's running sum: everything up to this round's end)
         __syncthreads();
     }
 }
@@ -803,7 +808,8 @@ __global__ void __launch_bounds__(1024) small_scan_kernel(const int *__restrict_
 static int exclusive_scan(const int *in, int *out, int64_t items, void *scratch, int64_t scratch_bytes, hipStream_t stream)
 {
     if (items <= kSmallScanItems) {
-        hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(1024), 0, stream, in, out, (int)items);
+        if (items <= 4096) hipLaunchKernelGGL(small_scan_kernel<4>, dim3(1), dim3(1024), 0, stream, in, out, (int)items);
+        else hipLaunchKernelGGL(small_scan_kernel<16>, dim3(1), dim3(1024), 0, stream, in, out, (int)items);
         NFFT_HIP_CHECK(hipGetLastError());
         return 0;
     }
