@@ -779,11 +779,20 @@ __global__ void __launch_bounds__(1024) small_scan_kernel(const int *__restrict_
         const int i0 = base + IPT * (int)threadIdx.x;
         int v[IPT];
         int mine = 0;
+        if (i0 + IPT <= items && ((uintptr_t)in & 15) == 0) {
+            // (16-byte loads: as single words a thread's 16 items were 16 load instructions of 64-byte stride across the lanes --
+            // 47 us for 23 500 items)
 #pragma unroll
-        for (int k = 0; k < IPT; ++k) {
-            v[k] = i0 + k < items ? in[i0 + k] : 0;
-            mine += v[k];
+            for (int k = 0; k < IPT; k += 4) {
+                const int4 q = *(const int4 *)(in + i0 + k);
+                v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) v[k] = i0 + k < items ? in[i0 + k] : 0;
         }
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) mine += v[k];
         int incl = mine;
         for (int off = 1; off < 64; off <<= 1) {
             const int t = __shfl_up(incl, off);
@@ -794,10 +803,22 @@ __global__ void __launch_bounds__(1024) small_scan_kernel(const int *__restrict_
         int before = carry_s;
         for (int w = 0; w < wave; ++w) before += wave_sums[w];
         int run = before + incl - mine;
+        if (i0 + IPT <= items && ((uintptr_t)out & 15) == 0) {
 #pragma unroll
-        for (int k = 0; k < IPT; ++k) {
-            if (i0 + k < items) out[i0 + k] = run;
-            run += v[k];
+            for (int k = 0; k < IPT; k += 4) {
+                int4 q;
+                q.x = run; run += v[k];
+                q.y = run; run += v[k + 1];
+                q.z = run; run += v[k + 2];
+                q.w = run; run += v[k + 3];
+                *(int4 *)(out + i0 + k) = q;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                if (i0 + k < items) out[i0 + k] = run;
+                run += v[k];
+            }
         }
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = run;  // (the last thread's running sum: everything up to this round's end)
