@@ -152,6 +152,29 @@ def test_column_fft_sizes_3d(tn, N, m):
     assert rel_l2(host(yf), nfft_ref.nfft_forward(xh, pos, None, m=m)) < tol
 
 
+@pytest.mark.parametrize("N,m,cols,complex_x", [(64, 4, (), False), (64, 2, (3,), True), (128, 4, (), True), (128, 3, (2,), False),
+                                               (256, 4, (), False), (512, 2, (), True)])
+def test_column_fft_sizes_2d(tn, N, m, cols, complex_x):
+    """2-D grids of 128^2 ... 1024^2 (round 4): own row pass + ONE pruned column pass that carries the roll-off instead of
+    rocFFT's 2-D transform and the roll-off kernel (taken from 2048 grid rows per call up: a single small grid is five
+    workgroups for them) -- both directions, both real_output settings, one and several columns (planar passes + layout
+    transpose), four point sets, against the float64 algorithm restatement."""
+    rng = np.random.default_rng(2000 + N + m)
+    n, B = 2500, 4  # (four point sets: all cases but the first have the >= 2048 grid rows the own passes are used from)
+    pos, batch, x = _random_problem(rng, 2, n, B, cols, complex_x)
+    for real_output in (False, True):
+        ya = tn.nfft_adjoint(dev(x), dev(pos), dev(batch), bandwidth=N, cutoff=m, real_output=real_output)
+        assert ya.shape == (B, N, N) + cols and ya.dtype == (torch.float32 if real_output else torch.complex64)
+        assert rel_l2(host(ya), nfft_ref.nfft_adjoint(x, pos, batch, N=N, m=m, real_output=real_output)) < T1N
+    xh = rng.standard_normal((B, N, N) + cols).astype(np.float32)
+    if complex_x:
+        xh = (xh + 1j * rng.standard_normal(xh.shape)).astype(np.complex64)
+    for real_output in (False, True):
+        yf = tn.nfft_forward(dev(xh), dev(pos), dev(batch), cutoff=m, real_output=real_output)
+        assert yf.shape == (n,) + cols and yf.dtype == (torch.float32 if real_output else torch.complex64)
+        assert rel_l2(host(yf), nfft_ref.nfft_forward(xh, pos, batch, m=m, real_output=real_output)) < T1N
+
+
 @pytest.mark.parametrize("d", [1, 2, 3])
 def test_real_output_variants(tn, d):
     rng = np.random.default_rng(77 + d)

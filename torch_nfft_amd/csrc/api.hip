@@ -491,6 +491,10 @@ int make_carve(const nfft_hip_problem *p, int planes_per_col, bool need_xs, FftK
     c.half_cells = (int64_t)(c.g.M / 2 + 1);
     for (int a = 0; a < 2; ++a) c.half_cells *= c.g.Ma[a];
     c.colfft = colfft_supported(c.g) && colfft_enabled();
+    // 2-D: the own passes are one workgroup per tile of 16 spectrum columns and plane -- five workgroups for a single 256^2
+    // grid (config C2: 118 us per adjoint + forward against 103 with rocFFT's two kernels + the roll-off kernel); they pay
+    // from a few planes up (64 planes of 256^2: 337 against 356 us, 4 planes of 512^2: 119 against 137)
+    if (c.g.dim == 2 && c.total_planes * c.g.M < 2048) c.colfft = false;
     const FftKind fkind = c.colfft ? (kind == kR2C ? kR2CRows : kC2RRows) : kind;
     const int64_t plane_bytes = c.g.cells * 4 + c.half_cells * 8 + (c.colfft ? colfft_scratch_bytes(c.g, 1) : 0);
     // (the budget is a soft one: the group padding of the column-innermost passes, <= 15 planes of scratch, comes on top)
@@ -718,7 +722,7 @@ static int adjoint_impl(const nfft_hip_problem *p, const float *pos, const int64
                 // transpose brings it into the reference's column-interleaved layout
                 StageTimer t(kStageDeconv, s);
                 const int ppc_a = x_is_complex ? 2 : 1;
-                const int64_t K = c.g.N * (int64_t)c.g.N * c.g.N;
+                const int64_t K = c.g.dim == 2 ? c.g.N * (int64_t)c.g.N : c.g.N * (int64_t)c.g.N * c.g.N;
                 if (int rc = launch_colfft_adjoint(c.g, spec, own_rows, ws + c.off_col, c.chunk_planes, 1, x_is_complex, real_output, 0, np, grid, mult, mult_kind, s)) return rc;
                 if (int rc = launch_column_layout(true, grid, y, K, c.C, p0 / ppc_a, np / ppc_a, real_output ? 4 : 8, s)) return rc;
             } else {
@@ -775,7 +779,7 @@ static int forward_impl(const nfft_hip_problem *p, const float *pos, const int64
                 if (c.C > 1) {
                     // several columns: planar copy of this chunk's columns first (the grid buffer is free until the row pass)
                     StageTimer t(kStageDeconv, s);
-                    const int64_t K = c.g.N * (int64_t)c.g.N * c.g.N;
+                    const int64_t K = c.g.dim == 2 ? c.g.N * (int64_t)c.g.N : c.g.N * (int64_t)c.g.N * c.g.N;
                     if (int rc = launch_column_layout(false, xhat, grid, K, c.C, p0 / ppc, np / ppc, x_is_complex ? 8 : 4, s)) return rc;
                     if (int rc = launch_colfft_forward(c.g, grid, ws + c.off_col, c.chunk_planes, 1, x_is_complex, real_output, 0, np, spec, own_rows, s)) return rc;
                 } else {

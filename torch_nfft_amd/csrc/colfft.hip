@@ -36,6 +36,9 @@ struct ColGeom {
                         // NC * 8-byte runs the passes read and write start on their own 64 / 128-byte lines (rows of
                         // 129 complex numbers put every run across two lines: the passes fetched ~2x their input)
     int NB;             // band+ rows: N + 1
+    int NBm;            // rows of the MIDDLE axis in T: NB, or 1 for 2-D problems (no middle axis: T is the compact S itself, the
+                        // "axis 0" pass is the only column pass and carries the roll-off)
+    int two_d;
     int NC, logNC;      // columns per tile
     int TG;             // tiles that share a 128-byte line (16 / NC; 1: the XCD-aware tile mapping below is off)
     float param;        // pi/3 * m / N^2  (phi_hat_inv exponent scale)
@@ -381,7 +384,7 @@ adj_axis0_kernel(ColGeom cg_in, const float2 *__restrict__ tw, const float2 *__r
     if (c0 >= cg.KC) return;  // (a spare tile of the rounded-up launch)
     stage_twiddles(ltw, tw, cg.M, tid);
     const int64_t plane = XCOMPLEX ? col_local * 2 : col_local;
-    const int64_t pstride = (int64_t)cg.M * cg.NB * cg.KS;
+    const int64_t pstride = (int64_t)cg.M * cg.NBm * cg.KS;
     const float2 *src = T + plane * pstride + (int64_t)j1 * cg.KS;
     for (int part = 0; part < (XCOMPLEX ? 2 : 1); ++part) {
         float2 *const dstbuf = part ? buf2 : buf;
@@ -390,7 +393,7 @@ adj_axis0_kernel(ColGeom cg_in, const float2 *__restrict__ tw, const float2 *__r
                          [&](int idx) {
                              const int col = idx & (cg.NC - 1), u0 = idx >> cg.logNC;
                              const int k2 = c0 + col;
-                             return k2 < cg.KC ? srcp[(int64_t)u0 * cg.NB * cg.KS + k2] : make_float2(0.f, 0.f);
+                             return k2 < cg.KC ? srcp[(int64_t)u0 * cg.NBm * cg.KS + k2] : make_float2(0.f, 0.f);
                          },
                          [&](int idx, float2 v) { dstbuf[idx] = v; });
     }
@@ -400,8 +403,9 @@ adj_axis0_kernel(ColGeom cg_in, const float2 *__restrict__ tw, const float2 *__r
     const int64_t colg = col0 + col_local;
     const int64_t b = colg / C, c = colg - b * C;
     const int H = cg.H, N = cg.N;
-    const int k1 = j1 - H;
-    const float f1 = phi_hat_inv_f(abs(k1), cg.param);
+    const int k1 = cg.two_d ? 0 : j1 - H;  // (2-D: no middle axis -- frequency 0 of an axis of one cell, factor 1)
+    const float f1 = cg.two_d ? 1.0f : phi_hat_inv_f(abs(k1), cg.param);
+    const int64_t NN = cg.two_d ? (int64_t)N * N : (int64_t)N * N * N;
     for (int idx = tid; idx < (cg.NB << cg.logNC); idx += kFftThreads) {
         const int col = idx & (cg.NC - 1), j0 = idx >> cg.logNC;
         const int k2 = c0 + col;
@@ -415,18 +419,18 @@ adj_axis0_kernel(ColGeom cg_in, const float2 *__restrict__ tw, const float2 *__r
         if (k0 < H && k1 < H && k2 < H) {
             // direct: g_hat[k] = conj(F_re) + i conj(F_im)
             float re = (fr.x + fi.y) * fac, im = (-fr.y + fi.x) * fac;
-            const int64_t f = ((int64_t)(k0 + H) * N + (k1 + H)) * N + (k2 + H);
+            const int64_t f = cg.two_d ? (int64_t)(k0 + H) * N + (k2 + H) : ((int64_t)(k0 + H) * N + (k1 + H)) * N + (k2 + H);
             apply_mult(mult, mult_kind, f, re, im);
-            const int64_t o = (b * N * N * N + f) * C + c;
+            const int64_t o = (b * NN + f) * C + c;
             if (REAL_OUT) ((float *)yv)[o] = re;
             else ((float2 *)yv)[o] = make_float2(re, im);
         }
         if (k2 >= 1 && k0 > -H && k1 > -H) {
             // mirror: g_hat[-k] = F_re + i F_im
             float re = (fr.x - fi.y) * fac, im = (fr.y + fi.x) * fac;
-            const int64_t f = ((int64_t)(H - k0) * N + (H - k1)) * N + (H - k2);
+            const int64_t f = cg.two_d ? (int64_t)(H - k0) * N + (H - k2) : ((int64_t)(H - k0) * N + (H - k1)) * N + (H - k2);
             apply_mult(mult, mult_kind, f, re, im);
-            const int64_t o = (b * N * N * N + f) * C + c;
+            const int64_t o = (b * NN + f) * C + c;
             if (REAL_OUT) ((float *)yv)[o] = re;
             else ((float2 *)yv)[o] = make_float2(re, im);
         }
@@ -438,10 +442,11 @@ adj_axis0_kernel(ColGeom cg_in, const float2 *__restrict__ tw, const float2 *__r
 //   Re g = C2R( (a[-k] + conj(a[k])) / 2 ),  Im g = C2R( (a[-k] - conj(a[k])) / (2i) )     (e^{+} transforms)
 template <bool XCOMPLEX>
 __device__ __forceinline__ float2 band_value(const void *__restrict__ xhat, int64_t b, int64_t c, int64_t C, int N,
-                                             int H, int k0, int k1, int k2)
+                                             int H, int k0, int k1, int k2, const bool two_d = false)
 {
-    if (k0 < -H || k0 >= H || k1 < -H || k1 >= H || k2 < -H || k2 >= H) return make_float2(0.f, 0.f);
-    const int64_t idx = (((b * N + (k0 + H)) * N + (k1 + H)) * N + (k2 + H)) * C + c;
+    if (k0 < -H || k0 >= H || (!two_d && (k1 < -H || k1 >= H)) || k2 < -H || k2 >= H) return make_float2(0.f, 0.f);
+    const int64_t idx = two_d ? ((b * N + (k0 + H)) * N + (k2 + H)) * C + c
+                              : (((b * N + (k0 + H)) * N + (k1 + H)) * N + (k2 + H)) * C + c;
     if (XCOMPLEX) return ((const float2 *)xhat)[idx];
     return make_float2(((const float *)xhat)[idx], 0.f);
 }
@@ -475,16 +480,16 @@ fwd_axis0_kernel(ColGeom cg_in, const float2 *__restrict__ tw, const void *__res
     const int part = (int)(plane - colg * ppc);
     const int64_t b = colg / C, c = colg - b * C;
     const int H = cg.H;
-    const int k1 = j1 - H;
-    const float f1 = phi_hat_inv_f(abs(k1), cg.param);
+    const int k1 = cg.two_d ? 0 : j1 - H;
+    const float f1 = cg.two_d ? 1.0f : phi_hat_inv_f(abs(k1), cg.param);
     batched_fill<8>(cg.NB << cg.logNC, tid,
                     [&](int idx) {
                         const int col = idx & (cg.NC - 1), j0 = idx >> cg.logNC;
                         const int k2 = c0 + col;
                         if (k2 >= cg.KC) return make_float2(0.f, 0.f);
                         const int k0 = j0 - H;
-                        const float2 ap = band_value<XCOMPLEX>(xhat, b, c, C, cg.N, H, k0, k1, k2);
-                        const float2 am = band_value<XCOMPLEX>(xhat, b, c, C, cg.N, H, -k0, -k1, -k2);
+                        const float2 ap = band_value<XCOMPLEX>(xhat, b, c, C, cg.N, H, k0, k1, k2, cg.two_d != 0);
+                        const float2 am = band_value<XCOMPLEX>(xhat, b, c, C, cg.N, H, -k0, -k1, -k2, cg.two_d != 0);
                         const float fac = 0.5f * phi_hat_inv_f(abs(k0), cg.param) * f1 * phi_hat_inv_f(k2, cg.param);
                         if (part == 0) return make_float2((am.x + ap.x) * fac, (am.y - ap.y) * fac);
                         return make_float2((am.y + ap.y) * fac, -(am.x - ap.x) * fac);
@@ -494,11 +499,11 @@ fwd_axis0_kernel(ColGeom cg_in, const float2 *__restrict__ tw, const void *__res
                         if (c0 + col < cg.KC) buf[(((j0 - H) & (cg.M - 1)) << cg.logNC) + col] = v;
                     });
     lds_fft<true>(buf, ltw, cg, tid);
-    float2 *dst = T + pl * ((int64_t)cg.M * cg.NB * cg.KS) + (int64_t)j1 * cg.KS;
+    float2 *dst = T + pl * ((int64_t)cg.M * cg.NBm * cg.KS) + (int64_t)j1 * cg.KS;
     for (int idx = tid; idx < (cg.M << cg.logNC); idx += kFftThreads) {
         const int col = idx & (cg.NC - 1), u0 = idx >> cg.logNC;
         const int k2 = c0 + col;
-        if (k2 < cg.KC) dst[(int64_t)u0 * cg.NB * cg.KS + k2] = buf[(brev_row(u0, cg.logM) << cg.logNC) + col];
+        if (k2 < cg.KC) dst[(int64_t)u0 * cg.NBm * cg.KS + k2] = buf[(brev_row(u0, cg.logM) << cg.logNC) + col];
     }
 }
 
@@ -1171,6 +1176,8 @@ ColGeom make_col_geom(const Geom &g, bool two_buffers, bool compact)
     cg.KS = compact_stride(g);
     cg.SR = compact ? cg.KS : cg.Mh;
     cg.NB = g.N + 1;
+    cg.two_d = g.dim == 2;
+    cg.NBm = cg.two_d ? 1 : cg.NB;
     // tile of NC columns: M * NC * 8 bytes per buffer.  32 KB tiles (NC = 8 at M = 512) let four workgroups share a
     // CU and overlap their load / transform / store phases: 6 % faster than 64 KB tiles, 16 KB tiles (64-byte row
     // segments) lose 30 %; NFFT_HIP_COL_NC overrides.
@@ -1216,13 +1223,21 @@ void allow_lds(K kernel, size_t bytes)
 
 bool colfft_supported(const Geom &g)
 {
+    // 3-D, and (round 4) 2-D grids the own row passes take: row pass + ONE column pass with the roll-off instead of rocFFT's
+    // two kernels + the roll-off kernel (three launches per direction -> two; NFFT_HIP_COLFFT_2D=0: rocFFT as before)
+    static const bool no2d = [] {
+        const char *env = std::getenv("NFFT_HIP_COLFFT_2D");
+        return env && env[0] == '0';
+    }();
+    if (g.dim == 2) return !no2d && g.M >= 128 && g.M <= 1024 && (g.M & (g.M - 1)) == 0;
     return g.dim == 3 && g.M >= 16 && g.M <= 1024 && (g.M & (g.M - 1)) == 0;
 }
 
 int64_t colfft_scratch_bytes(const Geom &g, int64_t nplanes)
 {
     // T[plane][M][N+1][KS] complex (+ room that used to hold a twiddle table; the workspace contract keeps its size)
-    return align_up(nplanes * (int64_t)g.M * (g.N + 1) * compact_stride(g) * 8, 256) + align_up((int64_t)g.M * 4, 256);
+    // (2-D: no T -- the column pass reads / writes the compact half spectrum itself)
+    return align_up(nplanes * (int64_t)g.M * (g.dim == 2 ? 1 : g.N + 1) * compact_stride(g) * 8, 256) + align_up((int64_t)g.M * 4, 256);
 }
 
 // Calls f(log2 M, log2 NC) as integral constants for the sizes the column kernels are specialised for -- 512^3 grids
@@ -1248,17 +1263,20 @@ int launch_colfft_adjoint(const Geom &g, const float2 *spec, bool compact, void 
                           const void *mult, int mult_kind, hipStream_t stream)
 {
     if (nplanes <= 0) return 0;
-    float2 *T = (float2 *)scratch;
+    const float2 *T = (const float2 *)scratch;
     const float2 *tw = twiddle_table(g.M);
     if (!tw) { set_error("no twiddle table for this grid size"); return 4; }
-    {
+    if (g.dim == 2) {
+        if (!compact) { set_error("2-D column passes need the compact half spectrum of the own row passes"); return 4; }
+        T = spec;  // S[plane][u1][KS]: the only column pass transforms it in place of T
+    } else {
         const ColGeom cg = make_col_geom(g, false, compact);
         const dim3 grid(col_tiles(cg), g.M, (unsigned)nplanes);
         const size_t lds = col_lds_bytes(cg, false);
         col_dispatch(cg, [&](auto lm, auto ln) {
             constexpr int LM = decltype(lm)::value, LN = decltype(ln)::value;
             allow_lds(adj_axis1_kernel<LM, LN>, lds);
-            hipLaunchKernelGGL((adj_axis1_kernel<LM, LN>), grid, dim3(kFftThreads), lds, stream, cg, tw, spec, T);
+            hipLaunchKernelGGL((adj_axis1_kernel<LM, LN>), grid, dim3(kFftThreads), lds, stream, cg, tw, spec, (float2 *)scratch);
         });
     }
     {
@@ -1266,7 +1284,7 @@ int launch_colfft_adjoint(const Geom &g, const float2 *spec, bool compact, void 
         const ColGeom cg = make_col_geom(g, two, compact);
         const int ppc = two ? 2 : 1;
         const int64_t col0 = plane0 / ppc, ncols = nplanes / ppc;
-        const dim3 grid(col_tiles(cg), cg.NB, (unsigned)ncols);
+        const dim3 grid(col_tiles(cg), cg.NBm, (unsigned)ncols);
         const size_t lds = col_lds_bytes(cg, two);
         col_dispatch(cg, [&](auto lm, auto ln) {
             constexpr int LM = decltype(lm)::value, LN = decltype(ln)::value;
@@ -1295,13 +1313,17 @@ int launch_colfft_forward(const Geom &g, const void *xhat, void *scratch, int64_
     float2 *T = (float2 *)scratch;
     const float2 *tw = twiddle_table(g.M);
     if (!tw) { set_error("no twiddle table for this grid size"); return 4; }
+    if (g.dim == 2) {
+        if (!compact) { set_error("2-D column passes need the compact half spectrum of the own row passes"); return 4; }
+        T = spec;  // the only column pass writes the compact half spectrum the row pass reads
+    }
     const ColGeom cg = make_col_geom(g, false, compact);
     const size_t lds = col_lds_bytes(cg, false);
     const int ppc = real_output ? 1 : 2;
     col_dispatch(cg, [&](auto lm, auto ln) {
         constexpr int LM = decltype(lm)::value, LN = decltype(ln)::value;
         {
-            const dim3 grid(col_tiles(cg), cg.NB, (unsigned)nplanes);
+            const dim3 grid(col_tiles(cg), cg.NBm, (unsigned)nplanes);
             if (x_is_complex) {
                 allow_lds(fwd_axis0_kernel<LM, LN, true>, lds);
                 hipLaunchKernelGGL((fwd_axis0_kernel<LM, LN, true>), grid, dim3(kFftThreads), lds, stream, cg, tw, xhat, C, ppc, plane0, T);
@@ -1310,7 +1332,7 @@ int launch_colfft_forward(const Geom &g, const void *xhat, void *scratch, int64_
                 hipLaunchKernelGGL((fwd_axis0_kernel<LM, LN, false>), grid, dim3(kFftThreads), lds, stream, cg, tw, xhat, C, ppc, plane0, T);
             }
         }
-        {
+        if (g.dim != 2) {
             const dim3 grid(col_tiles(cg, compact ? cg.KC : cg.Mh), g.M, (unsigned)nplanes);
             allow_lds(fwd_axis1_kernel<LM, LN>, lds);
             hipLaunchKernelGGL((fwd_axis1_kernel<LM, LN>), grid, dim3(kFftThreads), lds, stream, cg, tw, T, spec);
@@ -1321,7 +1343,7 @@ int launch_colfft_forward(const Geom &g, const void *xhat, void *scratch, int64_
 }
 
 // ---- column-innermost pipeline (several coefficient columns): launchers ---------------------------------------------
-bool colfft_ci_supported(const Geom &g) { return colfft_supported(g) && g.M >= 128 && g.M <= 1024; }
+bool colfft_ci_supported(const Geom &g) { return g.dim == 3 && colfft_supported(g) && g.M >= 128 && g.M <= 1024; }
 
 // planes the buffers of a chunk of `nplanes` planes must hold in column-innermost mode (whole groups of 16)
 int64_t colfft_ci_planes(int64_t nplanes) { return (nplanes + kCiQ - 1) / kCiQ * kCiQ; }
@@ -1462,7 +1484,7 @@ static void launch_rows_t(bool c2r, const Geom &g, int64_t nrows, const float2 *
 static int launch_rows(bool c2r, const Geom &g, int64_t nplanes, const float2 *tw, const void *in, void *out,
                        hipStream_t stream)
 {
-    const int64_t nrows = nplanes * g.M * g.M;
+    const int64_t nrows = nplanes * g.Ma[0] * g.Ma[1];  // (2-D: M rows per plane)
     // (the kept band of a row is N/2 + 1 of its M/2 = N complex points: what the C2R pass's single load per element assumes)
     switch (g.M) {
     case 128: launch_rows_t<6>(c2r, g, nrows, tw, in, out, stream); break;
