@@ -156,11 +156,10 @@ def test_column_fft_sizes_3d(tn, N, m):
                                                (256, 4, (), False), (512, 2, (), True)])
 def test_column_fft_sizes_2d(tn, N, m, cols, complex_x):
     """2-D grids of 128^2 ... 1024^2 (round 4): own row pass + ONE pruned column pass that carries the roll-off instead of
-    rocFFT's 2-D transform and the roll-off kernel (taken from 2048 grid rows per call up: a single small grid is five
-    workgroups for them) -- both directions, both real_output settings, one and several columns (planar passes + layout
+    rocFFT's 2-D transform and the roll-off kernel (column tiles of 4 ... 16 spectrum columns, by the plane count) -- both directions, both real_output settings, one and several columns (planar passes + layout
     transpose), four point sets, against the float64 algorithm restatement."""
     rng = np.random.default_rng(2000 + N + m)
-    n, B = 2500, 4  # (four point sets: all cases but the first have the >= 2048 grid rows the own passes are used from)
+    n, B = 2500, 4
     pos, batch, x = _random_problem(rng, 2, n, B, cols, complex_x)
     for real_output in (False, True):
         ya = tn.nfft_adjoint(dev(x), dev(pos), dev(batch), bandwidth=N, cutoff=m, real_output=real_output)

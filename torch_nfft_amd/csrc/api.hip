@@ -491,10 +491,6 @@ int make_carve(const nfft_hip_problem *p, int planes_per_col, bool need_xs, FftK
     c.half_cells = (int64_t)(c.g.M / 2 + 1);
     for (int a = 0; a < 2; ++a) c.half_cells *= c.g.Ma[a];
     c.colfft = colfft_supported(c.g) && colfft_enabled();
-    // 2-D: the own passes are one workgroup per tile of 16 spectrum columns and plane -- five workgroups for a single 256^2
-    // grid (config C2: 118 us per adjoint + forward against 103 with rocFFT's two kernels + the roll-off kernel); they pay
-    // from a few planes up (64 planes of 256^2: 337 against 356 us, 4 planes of 512^2: 119 against 137)
-    if (c.g.dim == 2 && c.total_planes * c.g.M < 2048) c.colfft = false;
     const FftKind fkind = c.colfft ? (kind == kR2C ? kR2CRows : kC2RRows) : kind;
     const int64_t plane_bytes = c.g.cells * 4 + c.half_cells * 8 + (c.colfft ? colfft_scratch_bytes(c.g, 1) : 0);
     // (the budget is a soft one: the group padding of the column-innermost passes, <= 15 planes of scratch, comes on top)

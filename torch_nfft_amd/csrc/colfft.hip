@@ -1163,7 +1163,7 @@ int compact_stride(const Geom &g)
     return (g.N / 2 + 1 + a - 1) / a * a;
 }
 
-ColGeom make_col_geom(const Geom &g, bool two_buffers, bool compact)
+ColGeom make_col_geom(const Geom &g, bool two_buffers, bool compact, int64_t planes = 0)
 {
     ColGeom cg;
     cg.M = g.M;
@@ -1184,6 +1184,11 @@ ColGeom make_col_geom(const Geom &g, bool two_buffers, bool compact)
     int nc = 16;
     const int64_t cap = g.M >= 1024 ? 65536 : 32768;
     while (nc > 1 && (int64_t)g.M * nc * 8 * (two_buffers ? 2 : 1) > cap) nc >>= 1;
+    // 2-D: a launch is (column tiles) x (planes) workgroups -- a single 256^2 grid is 5 tiles of 16 columns, a latency chain
+    // (config C2: 95 us per adjoint + forward with 16-column tiles, 78 with 4-column ones, 89 through rocFFT): narrower tiles
+    // until the launch has ~64 workgroups
+    if (g.dim == 2 && planes > 0)
+        while (nc > 4 && ((g.N / 2 + 1 + nc - 1) / nc) * planes < 64) nc >>= 1;
     if (const char *env = std::getenv("NFFT_HIP_COL_NC")) {
         const int v = std::atoi(env);
         if ((v == 4 || v == 8 || v == 16) && (int64_t)g.M * v * 8 * (two_buffers ? 2 : 1) <= 131072) nc = v;
@@ -1281,9 +1286,9 @@ int launch_colfft_adjoint(const Geom &g, const float2 *spec, bool compact, void 
     }
     {
         const bool two = x_is_complex != 0;
-        const ColGeom cg = make_col_geom(g, two, compact);
         const int ppc = two ? 2 : 1;
         const int64_t col0 = plane0 / ppc, ncols = nplanes / ppc;
+        const ColGeom cg = make_col_geom(g, two, compact, ncols);
         const dim3 grid(col_tiles(cg), cg.NBm, (unsigned)ncols);
         const size_t lds = col_lds_bytes(cg, two);
         col_dispatch(cg, [&](auto lm, auto ln) {
@@ -1317,7 +1322,7 @@ int launch_colfft_forward(const Geom &g, const void *xhat, void *scratch, int64_
         if (!compact) { set_error("2-D column passes need the compact half spectrum of the own row passes"); return 4; }
         T = spec;  // the only column pass writes the compact half spectrum the row pass reads
     }
-    const ColGeom cg = make_col_geom(g, false, compact);
+    const ColGeom cg = make_col_geom(g, false, compact, nplanes);
     const size_t lds = col_lds_bytes(cg, false);
     const int ppc = real_output ? 1 : 2;
     col_dispatch(cg, [&](auto lm, auto ln) {
