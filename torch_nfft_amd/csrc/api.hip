@@ -316,7 +316,7 @@ bool prefer_narrow(const nfft_hip_problem *p)
 Geom problem_geom(const nfft_hip_problem *p)
 {
     Geom g = make_geom(p->dim, p->N, p->m, false, false, prefer_narrow(p));
-    if (g.CG > 1 && !stream_items(p->num_points, p->batch_size, device_cu_count())) g.CG = 1;
+    if (g.CG > 1 && !stream_items(p->num_points, p->batch_size, device_cu_count(), g.M)) g.CG = 1;
     return g;
 }
 PlanSet plan_set(const nfft_hip_problem *p)

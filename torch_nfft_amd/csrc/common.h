@@ -430,7 +430,16 @@ inline unsigned work_list_workgroups(int64_t n, int64_t nsets, int64_t pencils, 
 // item): 7 237 points per item at config C3, the minimum of 2 048 at C5, where the lock-step kernel stays ahead
 // (0.60 vs 0.83 ms); at 5e6 points (3 617 per item) the streamed kernel + column groups win by 0.1 ms per step.
 int stream_min_item_points();  // api.hip: 3000, or NFFT_HIP_STREAM_MIN (tuning)
-inline bool stream_items(int64_t n, int64_t nsets, int ncu) { return seg_target_points(n, nsets, ncu) >= stream_min_item_points(); }
+// ... and dense mid-size point sets (round 4): from 10^6 points per set at >= 0.1 points per grid cell the streamed gather and
+// the column-group order win although the items hold only the minimum of 2 048 points (N = 64, 10^6 points: plan + spreading +
+// gather 0.428 -> 0.402 ms, 2e6: 0.749 -> 0.678; N = 128, 4e6: 1.30 -> 1.19; a sparse 10^6 on a 512^3 grid loses: 0.89 -> 1.13)
+inline bool stream_items(int64_t n, int64_t nsets, int ncu, int M)
+{
+    if (seg_target_points(n, nsets, ncu) >= stream_min_item_points()) return true;
+    const double per_set = (double)n / (double)(nsets > 0 ? nsets : 1);
+    return stream_min_item_points() == 3000 /* (not under a tuning override) */ && per_set >= 1.0e6 &&
+           per_set >= 0.1 * (double)M * (double)M * (double)M;
+}
 int device_cu_count();  // api.hip: CU count of the current device
 int current_device();
 // "done once per device" flag for per-kernel set-up (hipFuncSetAttribute is per device): a process may drive several

@@ -513,7 +513,7 @@ bool interp_stream_pays(const Geom &g, const PlanLayout &L, int64_t n)
 {
     int64_t nsets = g.tiles_per_batch > 0 ? L.ntiles / g.tiles_per_batch : 1;
     if (nsets < 1) nsets = 1;
-    return stream_items(n, nsets, device_cu_count());
+    return stream_items(n, nsets, device_cu_count(), g.M);
 }
 
 bool interp_stream_supported(const Geom &g)
