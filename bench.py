@@ -306,13 +306,15 @@ def main():
                                   "4 point sets x 100 000 uniform points (assumed; BASELINE.json gives no n), 64 real "
                                   "coefficient columns, forward with real_output", 3, 128, 4, p4, x4, b4,
                                   B4 * n4 * C4, "M point-columns/s")
-        # here HBM does bind the spreading stage: every (set, column) grid of 256^3 floats is written once
+        # every (set, column) grid of 256^3 floats is written once -- but the stage's time follows its K-block count, not these
+        # bytes (the same 17.2 GB take 4.9 ... 25.7 ms as the points per set go from 12 500 to 400 000: profiles/r04_experiments.md)
         alg4 = B4 * n4 * (4 * 3 + 4 * C4) + 8 * B4 * n4 + B4 * C4 * (256 ** 3) * 4
         sp4 = st4.get("spread", 0.0) + st4.get("zero", 0.0)
         if sp4 > 0:
             legs["C4-share"]["roofline"] = {
                 "stage": "zero-fill + spreading (all kernels between the sorted points and the finished grids)",
-                "bound": "hbm", "algorithmic_bytes_per_step": alg4, "ms_per_step": sp4,
+                "bound": "mfma", "bound_note": "the K-block pipeline of the matrix-core kernel (instruction issue + LDS round trips); "
+                "achieved / peak / frac are HBM figures by bytes written", "algorithmic_bytes_per_step": alg4, "ms_per_step": sp4,
                 "achieved": alg4 / (sp4 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": alg4 / (sp4 * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
@@ -496,9 +498,10 @@ def main():
                     "mfma_f16_issued_tflops": (mfma_flops / (sp_avg * 1e-3)) / 1e12 if sp_avg > 0 else 0.0,
                     "mfma_f16_peak_tflops": MFMA_F16_FLOPS / 1e12,
                     "frac_of_mfma_f16_peak": (mfma_flops / (sp_avg * 1e-3)) / MFMA_F16_FLOPS if sp_avg > 0 else 0.0,
-                    "valu_plus_mfma_busy_frac_of_simd_cycles": 0.82,
-                    "busy_frac_source": "profiles/r03_pmc_sq_counters.txt (SQ_ACTIVE_INST_VALU x 4 + SQ_VALU_MFMA_BUSY_CYCLES over "
-                                        "the SIMD cycles of the launch; builder-measured, not re-measured by this run)",
+                    "valu_plus_mfma_busy_frac_of_simd_cycles": 0.80,
+                    "busy_frac_source": "profiles/r04_pmc_sq_counters.txt ((SQ_ACTIVE_INST_VALU x 4 + SQ_VALU_MFMA_BUSY_CYCLES) / (1 024 "
+                                        "SIMDs x launch duration x 2.0 GHz): (1.41e9 + 0.84e9) / 2.83e9; builder-measured, not "
+                                        "re-measured by this run)",
                 },
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": sp_avg,
