@@ -105,9 +105,10 @@ int nfft_hip_forward(const nfft_hip_problem *p, const float *pos, const void *xh
 int nfft_hip_plan_needed(const nfft_hip_problem *p);
 
 /* The same two transforms on an existing point plan (nfft_hip_plan_points below): the plan depends only on
- * (pos, batch, N, m) and on whether num_columns is 1 or larger (sparse 3-D problems: the spreading kernel's tiling of the
- * plan differs), and can be shared by any number of adjoint / forward calls on the same points with column counts of
- * the same class -- pass the same nfft_hip_problem to the plan and to its users.  The
+ * (pos, batch, dim, N, m) -- with them num_points and batch_size, from which the tiling is chosen -- and on whether
+ * num_columns is 1 or larger (sparse 3-D problems: the spreading kernel's tiling of the plan differs), and can be shared by
+ * any number of adjoint / forward calls on the same points with column counts of the same class -- pass the same
+ * nfft_hip_problem to the plan and to its users.  The
  * reference re-derives shifts and psi in every call but reuses them when sources.is_same(targets)
  * (core_cuda.cu:552-564).  The workspace sizes are those of the un-planned calls. */
 int nfft_hip_adjoint_planned(const nfft_hip_problem *p, const void *plan, const void *x, int x_is_complex,
