@@ -70,7 +70,9 @@ def test_fastsum_golden_g6(tn):
     assert np.abs(host(A) - g["exact_gauss"]).max() < 0.1     # N=8 truncation of the kernel's Fourier series
 
 
-@pytest.mark.parametrize("d,N,m", [(1, 32, 3), (2, 16, 3), (3, 16, 4), (3, 12, 2)])
+@pytest.mark.parametrize("d,N,m", [(1, 32, 3), (2, 16, 3), (3, 16, 4), (3, 12, 2),
+                                   (2, 64, 4), (2, 128, 3)])  # (2-D grids of 128^2 up: own row + column passes, the kernel
+                                                             # coefficients ride on the column pass of the adjoint)
 @pytest.mark.parametrize("complex_x", [False, True])
 def test_fastsum_vs_oracle(tn, d, N, m, complex_x):
     rng = np.random.default_rng(10 * d + N)
