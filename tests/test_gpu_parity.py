@@ -544,6 +544,43 @@ print("RESULT", e1, e2)
     assert float(line[1]) < T1 and float(line[2]) < T1
 
 
+@pytest.mark.parametrize("env_extra", [{}, {"NFFT_HIP_SMALL_NARROW": "0"}, {"NFFT_HIP_OWNED_PAIR": "0"}, {"NFFT_HIP_COLFFT_2D": "0"}],
+                         ids=["defaults", "wide-64^3", "unpaired-owned", "rocfft-2d"])
+def test_round4_selection_switches_match_oracle(env_extra):
+    """What round 4 made the default, and the path each switch brings back, against the oracle: the 64^3 grid (N = 32) with a
+    narrow window (narrow tiling by default / NFFT_HIP_SMALL_NARROW=0: the matrix-core kernels on 3 x 2 pencils), a sparse
+    128^3 problem with three columns (paired owner-computes spreading / NFFT_HIP_OWNED_PAIR=0: one sweep per column), a 2-D
+    256^2 grid with two point sets (own row + column passes / NFFT_HIP_COLFFT_2D=0: rocFFT + the roll-off kernel)."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+import torch_nfft_amd as tn
+from torch_nfft_amd import ops
+from oracle import nfft_ref
+rng = np.random.default_rng(44)
+worst = 0.0
+for d, N, m, n, B, C in ((3, 32, 3, 6000, 2, 1), (3, 32, 2, 3000, 1, 2), (3, 64, 4, 5000, 2, 3), (2, 128, 4, 8000, 2, 1)):
+    pos = (rng.random((n, d)) - 0.5).astype(np.float32)
+    batch = np.sort(rng.integers(0, B, n)).astype(np.int64); batch[0], batch[-1] = 0, B - 1
+    x = rng.standard_normal((n, C)).astype(np.float32)
+    pt, bt = torch.from_numpy(pos).cuda(), torch.from_numpy(batch).cuda()
+    y = tn.nfft_adjoint(torch.from_numpy(x).cuda(), pt, bt, bandwidth=N, cutoff=m)
+    ref = nfft_ref.nfft_adjoint(x, pos, batch, N=N, m=m)
+    worst = max(worst, np.linalg.norm(y.cpu().numpy() - ref) / np.linalg.norm(ref))
+    f = tn.nfft_forward(y, pt, bt, cutoff=m)
+    reff = nfft_ref.nfft_forward(y.cpu().numpy(), pos, batch, m=m)
+    worst = max(worst, np.linalg.norm(f.cpu().numpy() - reff) / np.linalg.norm(reff))
+ops.check_status()
+print("RESULT", worst)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    assert float(line[1]) < T1N, out.stdout
+
+
 @pytest.mark.parametrize("env_extra", [{"NFFT_HIP_WORK_LIST": "1"}, {"NFFT_HIP_WORK_LIST": "1", "NFFT_HIP_STREAM_MIN": "1"},
                                        {"NFFT_HIP_WORK_LIST": "1", "NFFT_HIP_OWNED": "0"}])
 def test_work_list_forced_on_a_uniform_input(env_extra):
